@@ -1,0 +1,265 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+It imports ``/root/reference/controllers/mppi_*.py`` unmodified, replaces the instance's
+``_calc_epsilon`` with an injected noise tensor (recipe: SURVEY.md section 8c), spies on
+``_compute_weight`` / ``_moving_average_filter`` to capture S, w and the pre/post-filter
+weighted noise, and stores inputs + the reference's outputs as ``.npz`` (plain arrays,
+``allow_pickle=False``).  Nothing of the reference's source is copied; fixtures are data.
+
+Library versions used for the committed fixtures are stored inside each file
+(reference pins numpy 1.26.4; these were taken under the version printed below, which
+matters for the race-car f32 path -- SURVEY.md H5).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+from oracle import philox  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _spy(obj, name, log):
+    orig = getattr(obj, name)
+
+    def wrapped(*a, **kw):
+        r = orig(*a, **kw)
+        args = list(a) + list(kw.values())
+        log.append((tuple(np.array(x, copy=True) if isinstance(x, np.ndarray) else x for x in args),
+                    np.array(r, copy=True)))
+        return r
+
+    setattr(obj, name, wrapped)
+
+
+def run_reference_iteration(ctrl, x0, eps, method):
+    """One `_calc_*` call on a reference controller with eps injected; returns captures."""
+    wlog, flog = [], []
+    ctrl._calc_epsilon = lambda *a, **kw: np.array(eps, copy=True)
+    if not hasattr(ctrl, "_spied"):
+        ctrl._wlog, ctrl._flog = wlog, flog
+        _spy(ctrl, "_compute_weight", ctrl._wlog)
+        _spy(ctrl, "_moving_average_filter", ctrl._flog)
+        ctrl._spied = True
+    else:
+        ctrl._wlog.clear()
+        ctrl._flog.clear()
+    idx_attr = "prev_way_point_idx" if hasattr(ctrl, "prev_way_point_idx") else "prev_waypoints_idx"
+    cap = {"idx_before": int(getattr(ctrl, idx_attr)), "u_prev_in": ctrl.u_prev.copy()}
+    u0, u, opt, smp = getattr(ctrl, method)(np.array(x0, copy=True))
+    cap["S"] = ctrl._wlog[0][0][0]
+    cap["w"] = ctrl._wlog[0][1]
+    cap["w_eps_raw"] = ctrl._flog[0][0][0]
+    cap["w_eps_filtered"] = ctrl._flog[0][1]
+    cap["u_returned"] = np.array(u, copy=True)
+    cap["u0_returned"] = np.array(u0, copy=True)
+    cap["optimal_traj"] = np.array(opt, copy=True)
+    cap["sampled_traj_list"] = np.array(smp, copy=True)
+    cap["idx_after"] = int(getattr(ctrl, idx_attr))
+    return cap
+
+
+def versions():
+    import scipy
+    return json.dumps({"numpy": np.__version__, "scipy": scipy.__version__,
+                       "python": sys.version.split()[0], "reference_tag": "2024_08_07"})
+
+
+def save(name, kwargs, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    meta = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in kwargs.items()}
+    arrays = {k: np.asarray(v) for k, v in arrays.items() if v is not None}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array(json.dumps(meta)),
+                        versions=np.array(versions()), **arrays)
+    print(f"wrote {name}.npz  ({sum(a.nbytes for a in arrays.values())/1e3:.1f} kB raw)")
+
+
+# ---------------------------------------------------------------------------------------
+# differential drive
+# ---------------------------------------------------------------------------------------
+
+def dd_main_kwargs(**over):
+    """Parameters of the reference's `__main__` (mppi_differential_drive.py:400-410)."""
+    from controllers.mppi_differential_drive import generate_point_trajectory
+    cx, cy, cyaw = generate_point_trajectory(np.array([0.0, 0.0]), np.array([10.0, -5.0]))
+    kw = dict(delta_t=0.1, ref_path=np.array([cx, cy, cyaw]).T, max_speed=5.0, max_omega=3.14,
+              num_samples_K=128, num_horizons_T=25, param_exploration=0.0001, param_lambda=1.0,
+              param_alpha=0.2, sigma=np.array([[0.1, 0.0], [0.0, 0.01]]),
+              stage_cost_weight=np.array([5.0, 5.0, 10.0]), terminal_cost_weight=np.array([5.0, 5.0, 10.0]),
+              visualize_optimal_traj=True, visualze_sampled_trajs=True)
+    kw.update(over)
+    return kw
+
+
+def dd_obs_kwargs(n_circles=2, **over):
+    """`_obs` `__main__` parameters (mppi_differential_drive_obs.py:436-452); the 8-circle
+    set is BASELINE config 3's."""
+    from controllers.mppi_differential_drive_obs import generate_point_trajectory
+    cx, cy, cyaw = generate_point_trajectory(np.array([0.0, 0.0]), np.array([5.0, 5.0]))
+    circles = [[2.0, 2.0, 0.4], [3.0, 3.5, 0.4]]
+    rng = np.random.default_rng(1234)
+    while len(circles) < n_circles:
+        x, y = rng.uniform(0.5, 4.5, 2)
+        if x * x + y * y > (0.4 + 0.5) ** 2:
+            circles.append([float(x), float(y), 0.4])
+    kw = dict(delta_t=0.1, ref_path=np.array([cx, cy, cyaw]).T, max_speed=5.0, max_omega=3.14,
+              num_samples_K=128, num_horizons_T=25, param_exploration=0.05, param_lambda=10.0,
+              param_alpha=0.98, sigma=np.array([[0.1, 0.0], [0.0, 0.01]]),
+              stage_cost_weight=10 * np.array([5.0, 6.0, 9.0]), terminal_cost_weight=10 * np.array([5.0, 6.0, 9.0]),
+              obstacle_circles=np.array(circles[:n_circles]), safety_margin_rate=0.8,
+              visualize_optimal_traj=True, visualze_sampled_trajs=True)
+    kw.update(over)
+    return kw
+
+
+def gen_diffdrive():
+    from controllers.mppi_differential_drive import MPPIAlgorithms as DD
+    from controllers.mppi_differential_drive_obs import MPPIAlgorithms as DDObs
+
+    def one(name, kw, x0, seed, cls=DD, u_prev=None, idx0=0, store_eps=True, store_traj=True):
+        c = cls(**kw)
+        if u_prev is not None:
+            c.u_prev[:] = u_prev
+        c.prev_way_point_idx = idx0
+        K, T = kw["num_samples_K"], kw["num_horizons_T"]
+        eps = philox.sample_epsilon(kw["sigma"], seed, 0, K, T)
+        cap = run_reference_iteration(c, np.array(x0, float), eps.astype(np.float64), "_calc_input_control")
+        arrays = dict(x0=np.array(x0, float), eps_seed=np.array(seed), **cap)
+        if store_eps:
+            arrays["eps"] = eps
+        if not store_traj:
+            arrays.pop("sampled_traj_list")
+        save(name, kw, arrays)
+
+    one("dd_c1_default", dd_main_kwargs(), [0, 0, 0], 11)
+    one("dd_c1_moderate", dd_main_kwargs(param_exploration=0.1), [0, 0, 0], 12)
+    T = 25
+    tt = np.arange(T)
+    u_nz = np.stack([1.5 + 0.5 * np.sin(0.3 * tt), 0.2 * np.cos(0.2 * tt)], axis=1)
+    one("dd_nonzero_u", dd_main_kwargs(param_exploration=0.02), [1.0, -0.4, -0.3], 13, u_prev=u_nz, idx0=5)
+    one("dd_clamped", dd_main_kwargs(max_speed=0.25, max_omega=0.08, param_exploration=0.05), [0.2, 0.1, 0.1], 14,
+        u_prev=u_nz * 0.2)
+    one("dd_path_end", dd_main_kwargs(param_exploration=0.05), [9.95, -4.9, -0.4], 15, idx0=90)
+    one("dd_viz_off", dd_main_kwargs(param_exploration=0.05, visualize_optimal_traj=False,
+                                     visualze_sampled_trajs=False), [0.5, -0.2, 0.0], 16, u_prev=u_nz * 3.0)
+    one("dd_small_T10", dd_main_kwargs(num_samples_K=100, num_horizons_T=10), [0, 0, 0], 17)
+    # BASELINE config 2's problem on the reference (7 s per iteration): eps by seed only.
+    big = dd_main_kwargs(num_samples_K=4096, num_horizons_T=50, visualize_optimal_traj=False,
+                         visualze_sampled_trajs=False)
+    one("dd_c2_k4096_default", big, [0, 0, 0], 21, store_eps=False, store_traj=False)
+    big2 = dict(big, param_exploration=0.1)
+    tt = np.arange(50)
+    u50 = np.stack([2.0 + 0.5 * np.sin(0.2 * tt), -0.1 + 0.1 * np.cos(0.1 * tt)], axis=1)
+    one("dd_c2_k4096_moderate", big2, [2.0, -1.1, -0.45], 22, u_prev=u50, idx0=12, store_eps=False,
+        store_traj=False)
+
+    # obstacles
+    one("dd_obs_m2", dd_obs_kwargs(2), [0, 0, 0.6], 31, cls=DDObs)
+    one("dd_obs_m8_collide", dd_obs_kwargs(8), [1.2, 1.3, 0.78], 32, cls=DDObs,
+        u_prev=np.tile([2.0, 0.0], (25, 1)), idx0=20)
+    one("dd_obs_m8_k1024", dd_obs_kwargs(8, num_samples_K=1024, num_horizons_T=50, visualze_sampled_trajs=False),
+        [0.3, 0.2, 0.7], 33, cls=DDObs, store_traj=False)
+
+    # closed loop, 12 iterations with the reference's own plant (:33-40, :305-367)
+    from controllers.mppi_differential_drive import DifferentialDrive
+    kw = dd_main_kwargs(param_exploration=0.05, num_samples_K=256, num_horizons_T=20,
+                        visualze_sampled_trajs=False, visualize_optimal_traj=False)
+    c = DD(**kw)
+    plant = DifferentialDrive(np.array([0.0, 0.0, 0.0]))
+    rec = {k: [] for k in ("x0", "u0_returned", "u_returned", "idx_after", "S_min", "S")}
+    for it in range(12):
+        state = plant.get_state()
+        eps = philox.sample_epsilon(kw["sigma"], 41, it, 256, 20)
+        cap = run_reference_iteration(c, state, eps.astype(np.float64), "_calc_input_control")
+        rec["x0"].append(state)
+        rec["u0_returned"].append(cap["u0_returned"])
+        rec["u_returned"].append(cap["u_returned"])
+        rec["idx_after"].append(cap["idx_after"])
+        rec["S_min"].append(cap["S"].min())
+        rec["S"].append(cap["S"])
+        plant.update_state(kw["delta_t"], state, cap["u0_returned"])
+    rec["final_state"] = plant.get_state()
+    save("dd_closed_loop", kw, dict(eps_seed=np.array(41), **{k: np.array(v) for k, v in rec.items()}))
+
+
+# ---------------------------------------------------------------------------------------
+# race car
+# ---------------------------------------------------------------------------------------
+
+def gen_racecar():
+    from controllers.mppi_race_car import MPPIRacecarController as RC
+    from controllers.mppi_race_car_obstacle import MPPIRacecarController as RCObs
+
+    base = dict(delta_t=0.05, wheel_base=2.5, max_steer_abs=0.523, max_accel_abs=2.0,
+                horizon_step_T=25, number_of_samples_K=128, param_exploration=0.01, param_lambda=50.0,
+                param_alpha=1.0, sigma=np.array([[0.5, 0.0], [0.0, 0.1]]),
+                stage_cost_weight=np.array([50.0, 50.0, 1.0, 20.0]),
+                terminal_cost_weight=np.array([50.0, 50.0, 1.0, 20.0]),
+                visualize_optimal_traj=True, visualze_sampled_trajs=True)
+
+    def one(name, cls, kw, path, x0, seed, u_prev=None, idx0=0, store_traj=True):
+        c = cls(**dict(kw, ref_path=path))
+        if u_prev is not None:
+            c.u_prev[:] = u_prev
+        c.prev_waypoints_idx = idx0
+        K, T = kw["number_of_samples_K"], kw["horizon_step_T"]
+        eps = philox.sample_epsilon(kw["sigma"], seed, 0, K, T)
+        cap = run_reference_iteration(c, np.array(x0, np.float32), eps, "_calc_control_input")
+        arrays = dict(x0=np.array(x0, np.float32), eps=eps, eps_seed=np.array(seed), ref_path=c.ref_path, **cap)
+        if not store_traj:
+            arrays.pop("sampled_traj_list")
+        save(name, kw, arrays)
+
+    helper = RCObs()
+    lem = helper.generate_lemniscate_trajectory(100, 10.0)       # mppi_race_car_obstacle.py:288-299
+    circ = RC().generate_simple_trajectory(100, 10.0)            # mppi_race_car.py:224-234
+    one("rc_circle", RC, base, circ, circ[0], 51)
+    one("rc_circle_gamma", RC, dict(base, param_alpha=0.9, param_lambda=20.0), circ, circ[7], 52,
+        u_prev=np.tile([0.1, 0.5], (25, 1)).astype(np.float32), idx0=5)
+    obs = dict(base, obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), collision_safety_margin_rat=1.5)
+    one("rc_obs_default", RCObs, obs, lem, lem[0], 53)
+    one("rc_obs_none_collided", RCObs, dict(obs, obstacle_circles=np.array([[50.0, 50.0, 1.0]])), lem, lem[3], 54,
+        idx0=2)
+    one("rc_obs_all_collided", RCObs, dict(obs, obstacle_circles=np.array([[10.0, 0.0, 6.0], [8.0, 1.0, 3.0]])),
+        lem, lem[0], 55)
+    one("rc_obs_T75", RCObs, dict(obs, horizon_step_T=75, number_of_samples_K=96, visualze_sampled_trajs=False),
+        lem, lem[10], 56, idx0=8, store_traj=False)
+
+    # closed loop over the reference driver (mppi_race_car_obstacle.py:336-341: state = ref_path[i])
+    kw = dict(obs, number_of_samples_K=192, horizon_step_T=20, visualize_optimal_traj=False,
+              visualze_sampled_trajs=False)
+    c = RCObs(**dict(kw, ref_path=lem))
+    rec = {k: [] for k in ("x0", "u0_returned", "u_returned", "idx_after", "S")}
+    for it in range(8):
+        eps = philox.sample_epsilon(kw["sigma"], 61, it, 192, 20)
+        cap = run_reference_iteration(c, lem[it], eps, "_calc_control_input")
+        rec["x0"].append(lem[it])
+        rec["u0_returned"].append(cap["u0_returned"])
+        rec["u_returned"].append(cap["u_returned"])
+        rec["idx_after"].append(cap["idx_after"])
+        rec["S"].append(cap["S"])
+    save("rc_closed_loop", kw, dict(eps_seed=np.array(61), ref_path=lem, **{k: np.array(v) for k, v in rec.items()}))
+
+
+if __name__ == "__main__":
+    print("numpy", np.__version__)
+    which = sys.argv[1:] or ["dd", "rc"]
+    if "dd" in which:
+        gen_diffdrive()
+    if "rc" in which:
+        gen_racecar()

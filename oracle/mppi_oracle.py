@@ -1,0 +1,462 @@
+"""CPU restatement (NumPy) of the reference's MPPI iteration.  TEST INFRASTRUCTURE ONLY.
+
+This module is the *checker* for the HIP engine: only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``dnn-mppi-mpc_amd``) never does.
+
+Parity status: PINNED.  Every function here is checked against outputs of the reference
+itself (``tests/golden/*.npz``, written by ``oracle/gen_golden.py`` which imports
+``/root/reference/controllers/mppi_*.py`` unmodified with an injected noise tensor).
+
+All ``file:line`` citations are relative to ``/root/reference``.
+
+Two controller families are restated, quirks included:
+
+* ``DiffDriveOracle``  -- controllers/mppi_differential_drive.py:42-289 and
+  controllers/mppi_differential_drive_obs.py:42-313 (f64).
+* ``RaceCarOracle``    -- controllers/mppi_race_car.py:9-222 and
+  controllers/mppi_race_car_obstacle.py:10-274 (f32 under NumPy >= 2, NEP 50).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Shared stages
+# --------------------------------------------------------------------------------------
+
+
+def exploit_threshold(param_exploration: float, K: int) -> float:
+    """Real-valued split ``k < (1.0 - expl) * K`` (mppi_differential_drive.py:116)."""
+    return (1.0 - param_exploration) * K
+
+
+def sequential_sum(a: np.ndarray, axis: int = 0) -> np.ndarray:
+    """Left-to-right sum along ``axis`` in the array's dtype.
+
+    The reference accumulates with Python ``+=`` loops (mppi_differential_drive.py:132-135,
+    :173-175); ``np.cumsum`` is sequential (``np.sum`` is pairwise), so this reproduces
+    the loop's rounding.
+    """
+    return np.take(np.cumsum(a, axis=axis, dtype=a.dtype), -1, axis=axis)
+
+
+def moving_average_diffdrive(xx: np.ndarray, window_size: int = 10) -> np.ndarray:
+    """mppi_differential_drive.py:257-271 -- 'same' convolution plus the edge fix-ups,
+    including the ``xx_mean[-1]`` line that is hit ``n_conv-1`` times (bug kept)."""
+    b = np.ones(window_size) / window_size
+    dim = xx.shape[1]
+    xx_mean = np.zeros(xx.shape)
+    for d in range(dim):
+        xx_mean[:, d] = np.convolve(xx[:, d], b, mode="same")
+        n_conv = math.ceil(window_size / 2)
+        xx_mean[0, d] *= window_size / n_conv
+        for i in range(1, n_conv):
+            xx_mean[i, d] *= window_size / (i + n_conv)
+            xx_mean[-1, d] *= window_size / (i + n_conv - (window_size % 2))
+    return xx_mean
+
+
+def moving_average_racecar(xx: np.ndarray, window_size: int = 10) -> np.ndarray:
+    """mppi_race_car.py:211-222 -- pad with copies of the first/last 5 rows, 'same'
+    convolution, slice the padding off.  dtype follows ``xx`` (f32 in the reference)."""
+    ks = window_size
+    kernel = np.ones(ks, dtype=np.float32) / ks
+    dim = xx.shape[1]
+    xx_mean = np.zeros_like(xx)
+    for d in range(dim):
+        xx_padded = np.concatenate([xx[: ks // 2, d], xx[:, d], xx[-ks // 2:, d]], axis=0)
+        xx_mean[:, d] = np.convolve(xx_padded, kernel, mode="same")[ks // 2: -ks // 2]
+    return xx_mean
+
+
+def sequential_waypoint_scan(px, py, ref_xy, p, window):
+    """Thread the reference's single ``prev_way_point_idx`` through ``len(px)`` calls.
+
+    Call ``n`` does ``p <- p + argmin_{j < min(window, N-p)} d(pos_n, ref[p+j])`` (first
+    minimum), exactly mppi_differential_drive.py:201-220 with ``update_prev_idx=True``.
+    Returns (idx_used_by_call[n], p_final).  Vectorised by speculation: evaluate all
+    pending calls under the current ``p``, commit up to the first call that moves it.
+    """
+    n_calls = px.shape[0]
+    idx = np.empty(n_calls, dtype=np.int64)
+    n0 = 0
+    chunk = 32768
+    while n0 < n_calls:
+        n1 = min(n_calls, n0 + chunk)
+        win = ref_xy[p: p + window]
+        dx = px[n0:n1, None] - win[None, :, 0]
+        dy = py[n0:n1, None] - win[None, :, 1]
+        d = dx ** 2 + dy ** 2
+        am = np.argmin(d, axis=1)
+        moved = np.nonzero(am)[0]
+        if moved.size == 0:
+            idx[n0:n1] = p
+            n0 = n1
+            continue
+        f = int(moved[0])
+        idx[n0: n0 + f] = p
+        p = p + int(am[f])
+        idx[n0 + f] = p
+        n0 = n0 + f + 1
+    return idx, p
+
+
+# --------------------------------------------------------------------------------------
+# Differential drive (f64)
+# --------------------------------------------------------------------------------------
+
+
+class DiffDriveOracle:
+    """Restates ``MPPIAlgorithms`` (mppi_differential_drive.py:42-289; `_obs` :42-313)."""
+
+    SEARCH_IDX_LEN = 20  # mppi_differential_drive.py:204
+
+    def __init__(self, delta_t, ref_path, max_speed, max_omega, num_samples_K, num_horizons_T,
+                 param_exploration, param_lambda, param_alpha, sigma, stage_cost_weight,
+                 terminal_cost_weight, obstacle_circles=None, safety_margin_rate=None,
+                 visualize_optimal_traj=True, visualze_sampled_trajs=True):
+        self.delta_t = float(delta_t)
+        self.ref_path = np.asarray(ref_path, dtype=np.float64)
+        self.max_speed = float(max_speed)
+        self.max_omega = float(max_omega)
+        self.T = int(num_horizons_T)
+        self.K = int(num_samples_K)
+        self.param_exploration = float(param_exploration)
+        self.param_lambda = float(param_lambda)
+        self.param_alpha = float(param_alpha)
+        self.param_gamma = self.param_lambda * (1.0 - self.param_alpha)  # :74
+        self.Sigma = np.asarray(sigma, dtype=np.float64)
+        self.stage_cost_weight = np.asarray(stage_cost_weight, dtype=np.float64)
+        self.terminal_cost_weight = np.asarray(terminal_cost_weight, dtype=np.float64)
+        self.obstacle_circles = None if obstacle_circles is None else np.asarray(obstacle_circles, np.float64)
+        self.safety_margin_rate = safety_margin_rate
+        self.visualize_optimal_traj = visualize_optimal_traj
+        self.visualze_sampled_trajs = visualze_sampled_trajs
+        self.u_prev = np.zeros((self.T, 2))  # :82
+        self.prev_way_point_idx = 0  # :85
+
+    # -- stages -----------------------------------------------------------------------
+    def nearest_waypoint(self, x, y, p):
+        """:201-220 for one call; returns the new index."""
+        win = self.ref_path[p: p + self.SEARCH_IDX_LEN]
+        d = (x - win[:, 0]) ** 2 + (y - win[:, 1]) ** 2
+        return p + int(np.argmin(d))
+
+    def clamp(self, v):
+        """`_g` :285-289 (vectorised, returns a new array)."""
+        out = np.empty_like(v)
+        out[..., 0] = np.clip(v[..., 0], -self.max_speed, self.max_speed)
+        out[..., 1] = np.clip(v[..., 1], -self.max_omega, self.max_omega)
+        return out
+
+    def collided(self, x, y):
+        """`_is_collided` mppi_differential_drive_obs.py:301-313 (vectorised)."""
+        if self.obstacle_circles is None:
+            return np.zeros_like(x)
+        robot_radius = 0.5 * self.safety_margin_rate
+        hit = np.zeros(x.shape, dtype=bool)
+        for ox, oy, orad in self.obstacle_circles:
+            hit |= (x - ox) ** 2 + (y - oy) ** 2 < (robot_radius + orad) ** 2
+        return hit.astype(np.float64)
+
+    def rollout(self, x0, v):
+        """`_state_transition` :182-198 over all samples; v is the clamped [K,T,2]."""
+        K, T = v.shape[:2]
+        dt = self.delta_t
+        X = np.empty((K, T, 3))
+        x = np.full(K, x0[0], dtype=np.float64)
+        y = np.full(K, x0[1], dtype=np.float64)
+        yaw = np.full(K, x0[2], dtype=np.float64)
+        for t in range(T):
+            speed = v[:, t, 0]
+            omega = v[:, t, 1]
+            x, y, yaw = x + speed * np.cos(yaw) * dt, y + speed * np.sin(yaw) * dt, yaw + omega * dt
+            X[:, t, 0], X[:, t, 1], X[:, t, 2] = x, y, yaw
+        return X
+
+    def compute_weight(self, S):
+        """`_compute_weight` :167-180 (sequential eta)."""
+        rho = S.min()
+        e = np.exp(-(1.0 / self.param_exploration) * (S - rho))
+        eta = sequential_sum(e)
+        return (1 / eta) * e
+
+    # -- one iteration ------------------------------------------------------------------
+    def iteration(self, observed_x, epsilon):
+        """`_calc_input_control` :87-165 with ``epsilon`` injected in place of
+        `_calc_epsilon` :273-283.  Mutates ``u_prev`` / ``prev_way_point_idx`` like the
+        reference and returns every intermediate the fixtures record."""
+        K, T = self.K, self.T
+        x0 = np.asarray(observed_x, dtype=np.float64)
+        eps = np.asarray(epsilon, dtype=np.float64)
+        u = self.u_prev.copy()
+        out = {"idx_before": self.prev_way_point_idx}
+
+        # :96-99
+        p = self.nearest_waypoint(x0[0], x0[1], self.prev_way_point_idx)
+        out["path_end"] = bool(p >= self.ref_path.shape[0] - 1)
+        if out["path_end"]:
+            p = self.ref_path.shape[0] - 1
+        out["idx_start"] = p
+
+        # :116-121
+        thr = exploit_threshold(self.param_exploration, K)
+        exploit = (np.arange(K) < thr)[:, None, None]
+        v = self.clamp(np.where(exploit, u[None] + eps, eps))
+        X = self.rollout(x0, v)
+
+        # :124,:126 -- waypoint state threaded through K*(T+1) calls, k-major
+        px = np.concatenate([X[:, :, 0], X[:, -1:, 0]], axis=1).reshape(-1)
+        py = np.concatenate([X[:, :, 1], X[:, -1:, 1]], axis=1).reshape(-1)
+        idx, p = sequential_waypoint_scan(px, py, self.ref_path[:, :2], p, self.SEARCH_IDX_LEN)
+        idx = idx.reshape(K, T + 1)
+        i_stage, i_term = idx[:, T - 1], idx[:, T]
+        xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+        R = self.ref_path
+        w, wt = self.stage_cost_weight, self.terminal_cost_weight
+        coll = self.collided(xT, yT)
+        stage = (w[0] * (xT - R[i_stage, 0]) ** 2 + w[1] * (yT - R[i_stage, 1]) ** 2
+                 + w[2] * (yawT - R[i_stage, 2]) ** 2)
+        term = (wt[0] * (xT - R[i_term, 0]) ** 2 + wt[1] * (yT - R[i_term, 1]) ** 2
+                + wt[2] * (yawT - R[i_term, 2]) ** 2)
+        if self.obstacle_circles is not None:
+            stage = stage + coll * 1.0e10
+            term = term + coll * 1.0e10
+        q = u[T - 1].T @ np.linalg.inv(self.Sigma)  # :124, last step only survives
+        ctrl = self.param_gamma * (q[0] * v[:, T - 1, 0] + q[1] * v[:, T - 1, 1])
+        S = (stage + ctrl) + term
+        out["S"] = S
+        out["idx_after"] = p
+        self.prev_way_point_idx = p
+
+        wgt = self.compute_weight(S)
+        out["w"] = wgt
+        w_eps = sequential_sum(wgt[:, None, None] * eps, axis=0)  # :132-135
+        out["w_eps_raw"] = w_eps
+        w_eps = moving_average_diffdrive(w_eps, 10)  # :138
+        out["w_eps_filtered"] = w_eps
+        u = u + w_eps  # :141
+        out["u_pre_clamp"] = u.copy()
+        if self.visualze_sampled_trajs:  # :145-149 clamps every row of u in place
+            u = self.clamp(u)
+        out["u_pre_shift"] = u.copy()
+        # :162-165 (alias => returned u is the shifted sequence, u[0] the pre-shift u[1])
+        self.u_prev[:-1] = u[1:]
+        self.u_prev[-1] = u[-1]
+        out["u_returned"] = self.u_prev.copy()
+        out["u0_returned"] = self.u_prev[0].copy()
+        out["v"] = v
+        out["X"] = X
+        return out
+
+    def viz_trajectories(self, x0, u_pre_shift, v):
+        """:144-159 -- note the ``[t-1]`` indexing: step t is driven by control t-1 (t=0
+        wraps to the last row)."""
+        T = self.T
+        order = (np.arange(T) - 1) % T
+        opt = self.rollout(np.asarray(x0, np.float64), self.clamp(u_pre_shift[None, order]))[0]
+        smp = self.rollout(np.asarray(x0, np.float64), v[:, order])
+        return opt, smp
+
+
+# --------------------------------------------------------------------------------------
+# Race car (f32, NumPy >= 2 promotion rules)
+# --------------------------------------------------------------------------------------
+
+F32 = np.float32
+
+
+class RaceCarOracle:
+    """Restates ``MPPIRacecarController`` (mppi_race_car.py:9-222; `_obstacle` :10-274)."""
+
+    SEARCH_INDEX_LEN = 200  # mppi_race_car.py:158
+
+    def __init__(self, delta_t=0.05, wheel_base=2.5, max_steer_abs=0.523, max_accel_abs=2.0,
+                 ref_path=None, horizon_step_T=10, number_of_samples_K=100, param_exploration=0.01,
+                 param_lambda=50.0, param_alpha=1.0, sigma=None, stage_cost_weight=None,
+                 terminal_cost_weight=None, obstacle_circles=None, collision_safety_margin_rat=1.5,
+                 visualize_optimal_traj=True, visualze_sampled_trajs=True, raise_at_path_end=True):
+        self.T = int(horizon_step_T)
+        self.K = int(number_of_samples_K)
+        self.param_exploration = param_exploration
+        self.param_lambda = param_lambda
+        self.param_alpha = param_alpha
+        self.param_gamma = self.param_lambda * (1.0 - self.param_alpha)
+        sigma = np.array([[0.5, 0.0], [0.0, 0.1]]) if sigma is None else sigma
+        sw = np.array([50.0, 50.0, 1.0, 20.0]) if stage_cost_weight is None else stage_cost_weight
+        tw = np.array([50.0, 50.0, 1.0, 20.0]) if terminal_cost_weight is None else terminal_cost_weight
+        self.Sigma = np.asarray(sigma).astype(F32)
+        self.stage_cost_weight = np.asarray(sw).astype(F32)
+        self.terminal_cost_weight = np.asarray(tw).astype(F32)
+        self.delta_t = delta_t
+        self.wheel_base = wheel_base
+        self.max_steer_abs = max_steer_abs
+        self.max_accel_abs = max_accel_abs
+        self.ref_path = np.asarray(ref_path).astype(F32)
+        self.vehicle_w, self.vehicle_l = 3.0, 4.0  # mppi_race_car_obstacle.py:53-54
+        self.obstacle_circles = None if obstacle_circles is None else np.asarray(obstacle_circles, np.float64)
+        self.collision_safety_margin_rate = collision_safety_margin_rat
+        self.visualize_optimal_traj = visualize_optimal_traj
+        self.visualze_sampled_trajs = visualze_sampled_trajs
+        self.raise_at_path_end = raise_at_path_end
+        self.u_prev = np.zeros((self.T, 2), dtype=F32)
+        self.prev_waypoints_idx = 0
+
+    def nearest_waypoint(self, x, y, p):
+        """`get_nearest_waypoint` mppi_race_car.py:157-174, vectorised over calls."""
+        win = self.ref_path[p: p + self.SEARCH_INDEX_LEN]
+        dx = np.asarray(x, F32)[..., None] - win[:, 0]
+        dy = np.asarray(y, F32)[..., None] - win[:, 1]
+        d = dx ** 2 + dy ** 2
+        return p + np.argmin(d, axis=-1)
+
+    def clamp(self, v):
+        out = np.empty_like(v)
+        out[..., 0] = np.clip(v[..., 0], -self.max_steer_abs, self.max_steer_abs)
+        out[..., 1] = np.clip(v[..., 1], -self.max_accel_abs, self.max_accel_abs)
+        return out
+
+    def step(self, x, y, yaw, vel, steer, accel):
+        """`_F` mppi_race_car.py:183-197."""
+        l, dt = self.wheel_base, self.delta_t
+        new_x = x + vel * np.cos(yaw) * dt
+        new_y = y + vel * np.sin(yaw) * dt
+        new_yaw = yaw + vel / l * np.tan(steer) * dt
+        new_v = vel + accel * dt
+        return new_x, new_y, new_yaw, new_v
+
+    def rollout(self, x0, v):
+        K, T = v.shape[:2]
+        X = np.empty((K, T, 4), dtype=F32)
+        x = np.full(K, x0[0], F32)
+        y = np.full(K, x0[1], F32)
+        yaw = np.full(K, x0[2], F32)
+        vel = np.full(K, x0[3], F32)
+        for t in range(T):
+            x, y, yaw, vel = self.step(x, y, yaw, vel, v[:, t, 0], v[:, t, 1])
+            X[:, t, 0], X[:, t, 1], X[:, t, 2], X[:, t, 3] = x, y, yaw, vel
+        return X
+
+    def collided(self, x, y, yaw):
+        """`_is_collided` + `_affine_transform` mppi_race_car_obstacle.py:241-274: outline
+        points in f32, circle test in f64 (the circles stay a f64 array, :57)."""
+        if self.obstacle_circles is None:
+            return np.zeros(x.shape, dtype=F32)
+        vw = self.vehicle_w * self.collision_safety_margin_rate
+        vl = self.vehicle_l * self.collision_safety_margin_rate
+        sx = [-0.5 * vl, -0.5 * vl, 0.0, +0.5 * vl, +0.5 * vl, +0.5 * vl, 0.0, -0.5 * vl, -0.5 * vl]
+        sy = [0.0, +0.5 * vw, +0.5 * vw, +0.5 * vw, 0.0, -0.5 * vw, -0.5 * vw, -0.5 * vw, 0.0]
+        c, s = np.cos(yaw), np.sin(yaw)
+        hit = np.zeros(x.shape, dtype=bool)
+        for a, b in zip(sx, sy):
+            qx = F32(a) * c - F32(b) * s + x
+            qy = F32(a) * s + F32(b) * c + y
+            for ox, oy, orad in self.obstacle_circles:
+                hit |= (qx.astype(np.float64) - ox) ** 2 + (qy.astype(np.float64) - oy) ** 2 < orad ** 2
+        return hit.astype(F32)
+
+    def state_cost(self, X, p, weight):
+        """`_c` / `_phi` mppi_race_car.py:137-155 (obstacle variant :147-171) for states
+        X[...,4] with the waypoint search frozen at ``p``."""
+        x, y, yaw, vel = X[..., 0], X[..., 1], X[..., 2], X[..., 3]
+        two_pi = F32(2.0 * np.pi)
+        yaw_w = (yaw + two_pi) % two_pi
+        i = self.nearest_waypoint(x, y, p)
+        R = self.ref_path
+        c = (weight[0] * (x - R[i, 0]) ** 2 + weight[1] * (y - R[i, 1]) ** 2
+             + weight[2] * (yaw_w - R[i, 2]) ** 2 + weight[3] * (vel - R[i, 3]) ** 2)
+        if self.obstacle_circles is not None:
+            c = c + self.collided(x, y, yaw) * F32(1.0e10)
+        return c.astype(F32)
+
+    def compute_weight(self, S):
+        """`_compute_weight` mppi_race_car.py:199-209."""
+        rho = S.min()
+        e = np.exp(F32(-1.0 / self.param_lambda) * (S - rho))
+        eta = e.sum()
+        return (F32(1.0) / eta) * e
+
+    def iteration(self, observed_x, epsilon):
+        """`_calc_control_input` mppi_race_car.py:55-121 / obstacle :65-131."""
+        K, T = self.K, self.T
+        u = self.u_prev.copy()
+        x0 = np.asarray(observed_x).astype(F32)
+        eps = np.asarray(epsilon).astype(F32)
+        out = {"idx_before": self.prev_waypoints_idx}
+        p = int(self.nearest_waypoint(x0[0], x0[1], self.prev_waypoints_idx))
+        self.prev_waypoints_idx = p
+        out["idx_start"] = out["idx_after"] = p
+        out["path_end"] = bool(p >= self.ref_path.shape[0] - 1)
+        if out["path_end"] and self.raise_at_path_end:
+            raise IndexError("[ERROR] Reached the end of the reference path.")
+
+        thr = exploit_threshold(self.param_exploration, K)
+        exploit = (np.arange(K) < thr)[:, None, None]
+        v = self.clamp(np.where(exploit, u[None] + eps, eps)).astype(F32)
+        X = self.rollout(x0, v)
+        c = self.state_cost(X, p, self.stage_cost_weight)  # [K,T]
+        sinv = np.linalg.inv(self.Sigma)
+        q = np.matmul(sinv, v[..., None])[..., 0]  # inv(Sigma) @ v  -> [K,T,2]
+        ctrl = F32(self.param_gamma) * (u[None, :, 0] * q[..., 0] + u[None, :, 1] * q[..., 1])
+        S = sequential_sum((c + ctrl).astype(F32), axis=1)  # S[k] += ... in t order (:84)
+        S = (S + self.state_cost(X[:, -1], p, self.terminal_cost_weight)).astype(F32)
+        out["S"] = S
+        w = self.compute_weight(S)
+        out["w"] = w
+        w_eps = sequential_sum((w[:, None, None] * eps).astype(F32), axis=0)
+        out["w_eps_raw"] = w_eps
+        w_eps = moving_average_racecar(w_eps, 10)
+        out["w_eps_filtered"] = w_eps
+        u = (u + w_eps).astype(F32)
+        out["u_pre_clamp"] = u.copy()
+        if self.visualize_optimal_traj:  # :102-106 clamps u in place through `_g(u[t-1])`
+            u = self.clamp(u)
+        out["u_pre_shift"] = u.copy()
+        self.u_prev[:-1] = u[1:]
+        self.u_prev[-1] = u[-1]
+        out["u_returned"] = self.u_prev.copy()
+        out["u0_returned"] = self.u_prev[0].copy()
+        out["v"] = v
+        out["X"] = X
+        return out
+
+    def viz_trajectories(self, x0, u_pre_shift, v):
+        T = self.T
+        order = (np.arange(T) - 1) % T
+        x0 = np.asarray(x0).astype(F32)
+        opt = self.rollout(x0, self.clamp(u_pre_shift[None, order]))[0]
+        smp = self.rollout(x0, v[:, order])
+        return opt, smp
+
+
+# --------------------------------------------------------------------------------------
+# Plants and path generators (drivers)
+# --------------------------------------------------------------------------------------
+
+
+def diffdrive_plant_step(state, u, dt):
+    """`DifferentialDrive.update_state` mppi_differential_drive.py:33-40."""
+    x, y, yaw = state
+    return np.array([x + u[0] * np.cos(yaw) * dt, y + u[0] * np.sin(yaw) * dt, yaw + u[1] * dt])
+
+
+def generate_point_trajectory(start_point, end_point, num_points=100):
+    """mppi_differential_drive.py:385-389."""
+    x = np.linspace(start_point[0], end_point[0], num_points)
+    y = np.linspace(start_point[1], end_point[1], num_points)
+    yaw = np.arctan2(end_point[1] - start_point[1], end_point[0] - start_point[0]) * np.ones(num_points)
+    return np.array([x, y, yaw]).T
+
+
+def generate_lemniscate_racecar(num_points, radius):
+    """mppi_race_car_obstacle.py:288-299 (f32 linspace)."""
+    t = np.linspace(0, 2 * np.pi, num_points, dtype=np.float32)
+    a = radius
+    x = a * np.cos(t) / (1 + np.sin(t) ** 2)
+    y = a * np.sin(t) * np.cos(t) / (1 + np.sin(t) ** 2)
+    yaw = np.arctan2(np.gradient(y), np.gradient(x))
+    v = np.ones_like(t) * 5.0
+    return np.stack([x, y, yaw, v], axis=1)

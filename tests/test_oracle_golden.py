@@ -1,0 +1,91 @@
+"""CPU: the NumPy oracle reproduces what the reference itself produced (tests/golden)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import mppi_oracle, philox
+
+DD_SINGLE = [n for n in gu.names("dd_") if n != "dd_closed_loop"]
+RC_SINGLE = [n for n in gu.names("rc_") if n != "rc_closed_loop"]
+
+
+@pytest.mark.parametrize("name", DD_SINGLE)
+def test_diffdrive_iteration_matches_reference(name):
+    fx = gu.load(name)
+    o = gu.make_diffdrive_oracle(fx)
+    out = o.iteration(fx["x0"], gu.eps_of(fx).astype(np.float64))
+    # f64 path: the oracle restates the same arithmetic, so the match is to rounding.
+    np.testing.assert_allclose(out["S"], fx["S"], rtol=1e-13, atol=1e-13)
+    assert int(np.argmin(out["S"])) == int(np.argmin(fx["S"]))
+    np.testing.assert_allclose(out["w"], fx["w"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(out["w_eps_raw"], fx["w_eps_raw"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(out["w_eps_filtered"], fx["w_eps_filtered"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(out["u_returned"], fx["u_returned"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(out["u0_returned"], fx["u0_returned"], rtol=1e-9, atol=1e-14)
+    assert out["idx_after"] == int(fx["idx_after"])
+    if "sampled_traj_list" in fx and fx["meta"]["visualze_sampled_trajs"]:
+        opt, smp = o.viz_trajectories(fx["x0"], out["u_pre_shift"], out["v"])
+        np.testing.assert_allclose(opt, fx["optimal_traj"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(smp, fx["sampled_traj_list"], rtol=1e-10, atol=1e-12)
+
+
+def test_diffdrive_closed_loop_matches_reference():
+    fx = gu.load("dd_closed_loop")
+    o = mppi_oracle.DiffDriveOracle(**fx["meta"])
+    state = np.zeros(3)
+    for it in range(fx["x0"].shape[0]):
+        np.testing.assert_allclose(state, fx["x0"][it], rtol=1e-9, atol=1e-12)
+        out = o.iteration(state, gu.eps_of(fx, it).astype(np.float64))
+        np.testing.assert_allclose(out["S"], fx["S"][it], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(out["u_returned"], fx["u_returned"][it], rtol=1e-8, atol=1e-12)
+        assert out["idx_after"] == int(fx["idx_after"][it])
+        state = mppi_oracle.diffdrive_plant_step(state, out["u0_returned"], fx["meta"]["delta_t"])
+    np.testing.assert_allclose(state, fx["final_state"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", RC_SINGLE)
+def test_racecar_iteration_matches_reference(name):
+    fx = gu.load(name)
+    o = gu.make_racecar_oracle(fx)
+    out = o.iteration(fx["x0"], fx["eps"])
+    # f32 path: same dtype and op order as the reference, tolerance is a few f32 ulps of S
+    np.testing.assert_allclose(out["S"], fx["S"], rtol=2e-6)
+    np.testing.assert_allclose(out["w"], fx["w"], rtol=5e-4, atol=1e-12)
+    np.testing.assert_allclose(out["u_returned"], fx["u_returned"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(out["w_eps_filtered"], fx["w_eps_filtered"], rtol=1e-4, atol=2e-6)
+    assert out["idx_after"] == int(fx["idx_after"])
+    if "sampled_traj_list" in fx and fx["meta"]["visualze_sampled_trajs"]:
+        opt, smp = o.viz_trajectories(fx["x0"], out["u_pre_shift"], out["v"])
+        np.testing.assert_allclose(opt, fx["optimal_traj"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(smp, fx["sampled_traj_list"], rtol=1e-5, atol=1e-5)
+
+
+def test_racecar_closed_loop_matches_reference():
+    fx = gu.load("rc_closed_loop")
+    o = gu.make_racecar_oracle(fx)
+    for it in range(fx["x0"].shape[0]):
+        out = o.iteration(fx["x0"][it], gu.eps_of(fx, it))
+        np.testing.assert_allclose(out["S"], fx["S"][it], rtol=1e-5)
+        np.testing.assert_allclose(out["u_returned"], fx["u_returned"][it], rtol=1e-3, atol=1e-5)
+        assert out["idx_after"] == int(fx["idx_after"][it])
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x) for x in philox.philox4x32_10(*ctr, *key))
+        assert got == want
+
+
+def test_philox_sampler_moments():
+    sigma = np.array([[0.5, 0.1], [0.1, 0.2]])
+    e = philox.sample_epsilon(sigma, 7, 3, 4096, 50).reshape(-1, 2).astype(np.float64)
+    assert abs(e.mean(0)).max() < 5e-3
+    np.testing.assert_allclose(np.cov(e.T), sigma, atol=6e-3)
+    # shard invariance: rows depend on the global sample index only
+    part = philox.sample_epsilon(sigma, 7, 3, 100, 50, k_offset=1000)
+    np.testing.assert_array_equal(part, philox.sample_epsilon(sigma, 7, 3, 4096, 50)[1000:1100])
