@@ -1,0 +1,58 @@
+// Scalar math used by the rollout: one implementation per arithmetic type.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mf {
+
+// sin/cos of an fp32 angle: 3-term Cody-Waite reduction by pi/2 + degree-9/8 minimax
+// polynomials on [-pi/4, pi/4] (about 20 VALU ops, <= 2 ulp for |x| < 2^15).  Larger
+// arguments (a yaw that wound up thousands of turns; the reference never wraps it,
+// mppi_differential_drive.py:196) fall back to the library routine.
+__device__ __forceinline__ void sincos_poly(float r, int q, float &s, float &c) {
+    const float z = r * r;
+    float pc = 2.44677067e-5f;
+    pc = fmaf(pc, z, -1.38877297e-3f);
+    pc = fmaf(pc, z, 4.16666567e-2f);
+    pc = fmaf(pc, z, -5.00000000e-1f);
+    pc = fmaf(pc, z, 1.0f);
+    float ps = 2.86567956e-6f;
+    ps = fmaf(ps, z, -1.98559923e-4f);
+    ps = fmaf(ps, z, 8.33338592e-3f);
+    ps = fmaf(ps, z, -1.66666672e-1f);
+    ps = fmaf(ps, r * z, r);
+    const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ void sincos_(float x, float &s, float &c) {
+    if (__builtin_expect(fabsf(x) > 32768.0f, 0)) {
+        sincosf(x, &s, &c);
+        return;
+    }
+    const float kf = rintf(x * 6.36619747e-1f);
+    float r = fmaf(kf, -1.57079601e+00f, x);
+    r = fmaf(kf, -3.13916473e-07f, r);
+    r = fmaf(kf, -5.39030253e-15f, r);
+    sincos_poly(r, (int)kf, s, c);
+}
+__device__ __forceinline__ void sincos_(double x, double &s, double &c) { sincos(x, &s, &c); }
+
+// sin/cos(2*pi*u) for u in [0,1): exact reduction in quarter turns.
+__device__ __forceinline__ void sincos_turns(float u, float &s, float &c) {
+    const float q4 = 4.0f * u, kf = rintf(q4);
+    sincos_poly((q4 - kf) * 1.57079637e+00f, (int)kf, s, c);
+}
+
+__device__ __forceinline__ float tan_(float x) { return tanf(x); }
+__device__ __forceinline__ double tan_(double x) { return tan(x); }
+__device__ __forceinline__ float exp_(float x) { return expf(x); }
+__device__ __forceinline__ double exp_(double x) { return exp(x); }
+
+// Python's float `%` with a positive divisor (mppi_race_car.py:141): result in [0, m).
+__device__ __forceinline__ float pymod(float a, float m) { const float r = fmodf(a, m); return r < 0.f ? r + m : r; }
+__device__ __forceinline__ double pymod(double a, double m) { const double r = fmod(a, m); return r < 0.0 ? r + m : r; }
+
+template <typename R> __device__ __forceinline__ R clamp(R v, R lim) { return v < -lim ? -lim : (v > lim ? lim : v); }
+
+}  // namespace mf

@@ -1,0 +1,688 @@
+// C ABI of libmppi_hip.so (include/mppi_hip.h): handle management, parameter packing and
+// the launch sequence of one MPPI iteration.  No algorithmic arithmetic happens on the host.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mppi_hip.h"
+#include "mppi_kernels.h"
+
+using namespace mppi;
+
+static thread_local std::string g_create_error;
+
+struct mppi_handle {
+    mppi_config cfg;
+    bool f64 = false;
+    int nx = 3, n_ref = 0, n_obs = 0, n_blocks = 0, traj_per_block = 0;
+    void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
+    int *d_pout = nullptr;
+    double *d_partials = nullptr, *d_w = nullptr, *d_trace = nullptr;
+    long long trace_cap = 0;
+    DevState *d_st = nullptr;
+    StepResult *d_res = nullptr, *h_res = nullptr;
+    size_t res_bytes = 0;
+    const float *last_eps = nullptr;
+    bool last_philox = true, begun = false, timing = false;
+    long long iter = 0;
+    int idx = 0;
+    std::vector<hipEvent_t> ev;  // pairs around the rollout / reduce / finalize kernels
+    size_t ev_used = 0;
+    hipEvent_t ev_step[2] = {nullptr, nullptr};
+    float last_ms[4] = {0, 0, 0, 0};
+    std::string err;
+};
+
+#define FAIL(h, code, ...)                                   \
+    do {                                                     \
+        char _b[512];                                        \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);               \
+        if (h) (h)->err = _b; else g_create_error = _b;      \
+        return (code);                                       \
+    } while (0)
+
+#define HIPCHECK(h, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) FAIL(h, MPPI_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+
+extern "C" const char *mppi_last_error(const mppi_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mppi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static size_t rsz(const mppi_handle *h) { return h->f64 ? sizeof(double) : sizeof(float); }
+
+// host double[] -> device array in the kernel precision
+static int upload_real(mppi_handle *h, void *dst, const double *src, size_t n) {
+    if (h->f64) {
+        HIPCHECK(h, hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+        HIPCHECK(h, hipMemcpy(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return MPPI_OK;
+}
+
+static int download_real(mppi_handle *h, double *dst, const void *src, size_t n) {
+    if (h->f64) {
+        HIPCHECK(h, hipMemcpy(dst, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(n);
+        HIPCHECK(h, hipMemcpy(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
+    }
+    return MPPI_OK;
+}
+
+extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
+    if (!cfg || !out) FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(mppi_config))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: struct_size %d != %zu (ABI mismatch)",
+             cfg->struct_size, sizeof(mppi_config));
+    mppi_config c = *cfg;
+    if (c.K_global == 0) c.K_global = c.K;
+    if (c.K < 1 || c.T < 1 || c.K_global < c.K || c.k_offset < 0 || c.k_offset + c.K > c.K_global)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: bad K=%d T=%d K_global=%d k_offset=%d", c.K, c.T,
+             c.K_global, c.k_offset);
+    if (c.model != MPPI_MODEL_DIFFDRIVE && c.model != MPPI_MODEL_RACECAR)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown model %d", c.model);
+    if (c.precision != MPPI_PREC_F32 && c.precision != MPPI_PREC_F64)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown precision %d", c.precision);
+    if (c.filter_window < 1) c.filter_window = 10;
+    if (c.search_window < 1)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: search_window must be >= 1");
+    // the reference's filters fail on short horizons (np.convolve 'same' returns max(M, N) samples)
+    if (c.filter_mode == MPPI_FILTER_DIFFDRIVE && c.T < c.filter_window)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "horizon T=%d is shorter than the moving-average window %d", c.T,
+             c.filter_window);
+    if (c.filter_mode == MPPI_FILTER_RACECAR && c.T < c.filter_window / 2)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "horizon T=%d is shorter than half the filter window %d", c.T,
+             c.filter_window);
+    if (c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && c.K_global != c.K)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
+             "the sequential waypoint index threads through all samples in order and cannot be sharded; "
+             "use MPPI_WAYPOINT_FROZEN with K_global > K");
+    const double det = c.sigma[0] * c.sigma[3] - c.sigma[1] * c.sigma[2];
+    if (!(c.sigma[0] > 0) || !(det > 0))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "sigma must be a symmetric positive definite 2x2 matrix");
+    if (!(c.param_exploration >= 0) || !(c.param_lambda > 0))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "param_exploration must be >= 0 and param_lambda > 0");
+    if (c.beta_mode == MPPI_BETA_INV_EXPLORATION && !(c.param_exploration > 0))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "beta = 1/param_exploration needs param_exploration > 0");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_NO_DEVICE, "no HIP device is visible: libmppi_hip.so needs an MI355X");
+    if (c.device < 0 || c.device >= ndev)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_NO_DEVICE, "device %d out of range (%d visible)", c.device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device) != hipSuccess)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+             c.device, prop.gcnArchName);
+
+    mppi_handle *h = new mppi_handle();
+    h->cfg = c;
+    h->f64 = c.precision == MPPI_PREC_F64;
+    h->nx = c.model == MPPI_MODEL_RACECAR ? 4 : 3;
+    int tpb = 0;
+    if (const char *e = getenv("MPPI_TRAJ_PER_BLOCK")) tpb = atoi(e);
+    if (tpb < 1) tpb = (c.K + 127) / 128;
+    tpb = ((tpb + 3) / 4) * 4;
+    if (tpb > 2048) tpb = 2048;
+    h->traj_per_block = tpb;
+    h->n_blocks = reduce_blocks(c.K, tpb);
+    h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
+    auto fail = [&](hipError_t e, const char *what) {
+        g_create_error = std::string(what) + " failed: " + hipGetErrorString(e);
+        mppi_destroy(h);
+        return (int)MPPI_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(c.device)) != hipSuccess) return fail(e, "hipSetDevice");
+    const size_t r = rsz(h);
+    if ((e = hipMalloc(&h->d_u, r * 2 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u)");
+    if ((e = hipMalloc(&h->d_uhist, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
+    if ((e = hipMalloc(&h->d_S, r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
+    if ((e = hipMalloc((void **)&h->d_pout, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
+    if ((e = hipMalloc((void **)&h->d_partials, sizeof(double) * (size_t)(h->n_blocks + 1) * partial_len(c.T))) !=
+        hipSuccess)
+        return fail(e, "hipMalloc(partials)");
+    if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
+    if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
+    if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(result)");
+    if ((e = hipMemset(h->d_u, 0, r * 2 * c.T)) != hipSuccess) return fail(e, "hipMemset");        // u_prev = 0 (:82)
+    if ((e = hipMemset(h->d_uhist, 0, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_S, 0, r * c.K)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_pout, 0, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMemset");
+    DevState st0;
+    memset(&st0, 0, sizeof(st0));  // prev_way_point_idx = 0 (:85)
+    st0.first_k = NO_TRIGGER;
+    if ((e = hipMemcpy(h->d_st, &st0, sizeof(st0), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    memset(h->h_res, 0, h->res_bytes);
+    if ((e = hipEventCreate(&h->ev_step[0])) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->ev_step[1])) != hipSuccess) return fail(e, "hipEventCreate");
+    *out = h;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_destroy(mppi_handle *h) {
+    if (!h) return MPPI_OK;
+    hipSetDevice(h->cfg.device);
+    void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials,
+                    h->d_w,   h->d_trace, h->d_st, h->d_res};
+    for (void *b : bufs)
+        if (b) hipFree(b);
+    if (h->h_res) hipHostFree(h->h_res);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_step)
+        if (e) hipEventDestroy(e);
+    delete h;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_set_ref_path(mppi_handle *h, const double *path, int32_t n, int32_t ncols) {
+    if (!h || !path) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_ref_path: null argument");
+    const int need = h->cfg.model == MPPI_MODEL_RACECAR ? 4 : 3;
+    if (n < 1 || ncols < need || ncols > 4)
+        FAIL(h, MPPI_ERR_SHAPE, "ref_path must be [n>=1, %d] (got [%d, %d])", need, n, ncols);
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    std::vector<double> packed((size_t)n * 4, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < ncols; ++j) packed[(size_t)i * 4 + j] = path[(size_t)i * ncols + j];
+    HIPCHECK(h, hipDeviceSynchronize());
+    if (h->d_ref) HIPCHECK(h, hipFree(h->d_ref));
+    h->d_ref = nullptr;
+    HIPCHECK(h, hipMalloc(&h->d_ref, rsz(h) * 4 * n));
+    h->n_ref = n;
+    return upload_real(h, h->d_ref, packed.data(), packed.size());
+}
+
+extern "C" int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m) {
+    if (!h || (m > 0 && !xyr)) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_obstacles: null argument");
+    if (m < 0) FAIL(h, MPPI_ERR_SHAPE, "mppi_set_obstacles: m < 0");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    if (h->d_obs) HIPCHECK(h, hipFree(h->d_obs));
+    h->d_obs = nullptr;
+    h->n_obs = m;
+    if (m == 0) return MPPI_OK;
+    std::vector<double> packed((size_t)m * 4, 0.0);
+    for (int i = 0; i < m; ++i) {
+        const double r = xyr[3 * i + 2];
+        // mppi_differential_drive_obs.py:304-311: (0.5*margin + r)^2 ; mppi_race_car_obstacle.py:272: r^2
+        const double thr = h->cfg.obstacle_model == MPPI_OBSTACLE_CIRCLE ? 0.5 * h->cfg.safety_margin + r : r;
+        packed[4 * i] = xyr[3 * i];
+        packed[4 * i + 1] = xyr[3 * i + 1];
+        packed[4 * i + 2] = thr * thr;
+    }
+    HIPCHECK(h, hipMalloc(&h->d_obs, rsz(h) * 4 * m));
+    return upload_real(h, h->d_obs, packed.data(), packed.size());
+}
+
+extern "C" int mppi_set_u_prev(mppi_handle *h, const double *u) {
+    if (!h || !u) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_u_prev: null argument");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    return upload_real(h, h->d_u, u, (size_t)2 * h->cfg.T);
+}
+
+extern "C" int mppi_get_u_prev(mppi_handle *h, double *u) {
+    if (!h || !u) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_get_u_prev: null argument");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    return download_real(h, u, h->d_u, (size_t)2 * h->cfg.T);
+}
+
+extern "C" int mppi_set_waypoint_idx(mppi_handle *h, int32_t idx) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    if (idx < 0 || (h->n_ref > 0 && idx >= h->n_ref)) FAIL(h, MPPI_ERR_BAD_ARG, "waypoint index %d out of range", idx);
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(&h->d_st->p, &idx, sizeof(int), hipMemcpyHostToDevice));
+    h->idx = idx;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_get_waypoint_idx(mppi_handle *h, int32_t *idx) {
+    if (!h || !idx) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(idx, &h->d_st->p, sizeof(int), hipMemcpyDeviceToHost));
+    h->idx = *idx;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_set_iteration(mppi_handle *h, int64_t iteration) {
+    if (!h || iteration < 0) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    long long it = iteration;
+    HIPCHECK(h, hipMemcpy(&h->d_st->iter, &it, sizeof(it), hipMemcpyHostToDevice));
+    h->iter = it;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_set_state(mppi_handle *h, const double *x) {
+    if (!h || !x) return MPPI_ERR_BAD_ARG;
+    double v[4] = {0, 0, 0, 0};
+    for (int i = 0; i < h->nx; ++i) v[i] = x[i];
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(h->d_st->x0, v, sizeof(v), hipMemcpyHostToDevice));
+    return MPPI_OK;
+}
+
+extern "C" int mppi_get_state(mppi_handle *h, double *x) {
+    if (!h || !x) return MPPI_ERR_BAD_ARG;
+    double v[4];
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(v, h->d_st->x0, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->nx; ++i) x[i] = v[i];
+    return MPPI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter packing
+// ------------------------------------------------------------------------------------------
+template <typename R> static KParams<R> make_params(const mppi_handle *h, const float *eps) {
+    const mppi_config &c = h->cfg;
+    KParams<R> P;
+    memset(&P, 0, sizeof(P));
+    P.K = c.K;
+    P.T = c.T;
+    P.k_offset = c.k_offset;
+    const double thr = (1.0 - c.param_exploration) * c.K_global;  // k < thr, mppi_differential_drive.py:116
+    double ne = ceil(thr);
+    if (ne < 0) ne = 0;
+    if (ne > c.K_global) ne = c.K_global;
+    P.n_exploit = (int)ne;
+    P.n_ref = h->n_ref;
+    P.n_obs = c.obstacle_model == MPPI_OBSTACLE_NONE ? 0 : h->n_obs;
+    P.window = c.search_window;
+    P.model = c.model;
+    P.accumulate = c.accumulate_stage_cost;
+    P.sequential = c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL;
+    P.obstacle_model = P.n_obs > 0 ? c.obstacle_model : OBS_NONE;
+    P.clamp_rollout = c.clamp_rollout;
+    P.wrap_stage = c.wrap_yaw_stage;
+    P.wrap_term = c.wrap_yaw_terminal;
+    P.use_philox = eps == nullptr;
+    P.traj_per_block = h->traj_per_block;
+    P.seed_lo = (unsigned)(c.seed & 0xffffffffu);
+    P.seed_hi = (unsigned)(c.seed >> 32);
+    P.dt = (R)c.delta_t;
+    P.umax0 = (R)c.u_max[0];
+    P.umax1 = (R)c.u_max[1];
+    P.wheel_base = (R)c.wheel_base;
+    const double beta = c.beta_mode == MPPI_BETA_INV_EXPLORATION ? 1.0 / c.param_exploration
+                        : c.beta_mode == MPPI_BETA_INV_LAMBDA    ? 1.0 / c.param_lambda
+                                                                 : c.param_lambda;
+    P.beta = (R)beta;
+    P.gamma = (R)(c.param_lambda * (1.0 - c.param_alpha));  // :74
+    P.penalty = (R)c.collision_penalty;
+    P.two_pi = (R)(2.0 * M_PI);
+    const double det = c.sigma[0] * c.sigma[3] - c.sigma[1] * c.sigma[2];
+    const double si[4] = {c.sigma[3] / det, -c.sigma[1] / det, -c.sigma[2] / det, c.sigma[0] / det};
+    for (int i = 0; i < 4; ++i) {
+        P.sinv[i] = (R)si[i];
+        P.ws[i] = (R)c.stage_cost_weight[i];
+        P.wt[i] = (R)c.terminal_cost_weight[i];
+    }
+    // vehicle outline, mppi_race_car_obstacle.py:256-264
+    const double vw = c.vehicle_w * c.safety_margin, vl = c.vehicle_l * c.safety_margin;
+    const double sx[9] = {-0.5 * vl, -0.5 * vl, 0.0, 0.5 * vl, 0.5 * vl, 0.5 * vl, 0.0, -0.5 * vl, -0.5 * vl};
+    const double sy[9] = {0.0, 0.5 * vw, 0.5 * vw, 0.5 * vw, 0.0, -0.5 * vw, -0.5 * vw, -0.5 * vw, 0.0};
+    for (int i = 0; i < 9; ++i) {
+        P.shape_x[i] = (R)sx[i];
+        P.shape_y[i] = (R)sy[i];
+    }
+    const double l00 = sqrt(c.sigma[0]), l10 = c.sigma[2] / l00, l11 = sqrt(c.sigma[3] - l10 * l10);
+    P.chol[0] = (float)l00;
+    P.chol[1] = (float)l10;
+    P.chol[2] = (float)l11;
+    P.ref = (const R *)h->d_ref;
+    P.obs = (const R *)h->d_obs;
+    P.u = (const R *)h->d_u;
+    P.eps = eps;
+    P.S = (R *)h->d_S;
+    P.pout = h->d_pout;
+    P.st = h->d_st;
+    return P;
+}
+
+static FinalizeParams make_finalize(const mppi_handle *h, const double *partials, int n_part, int merge_only,
+                                    double *partial_out, int plant) {
+    const mppi_config &c = h->cfg;
+    FinalizeParams F;
+    memset(&F, 0, sizeof(F));
+    F.T = c.T;
+    F.K = c.K;
+    F.n_part = n_part;
+    F.merge_only = merge_only;
+    F.filter_mode = c.filter_mode;
+    F.filter_window = c.filter_window;
+    F.clamp_u = c.clamp_u_after_update;
+    F.raise_at_path_end = c.raise_at_path_end;
+    F.model = c.model;
+    F.sequential = c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL;
+    F.plant = plant;
+    F.n_ref = h->n_ref;
+    F.window = c.search_window;
+    F.is_f64 = h->f64;
+    F.beta = c.beta_mode == MPPI_BETA_INV_EXPLORATION ? 1.0 / c.param_exploration
+             : c.beta_mode == MPPI_BETA_INV_LAMBDA    ? 1.0 / c.param_lambda
+                                                      : c.param_lambda;
+    if (!h->f64) F.beta = (double)(float)F.beta;  // the block partials were scaled with the f32 rate
+    F.dt = c.delta_t;
+    F.wheel_base = c.wheel_base;
+    F.umax0 = c.u_max[0];
+    F.umax1 = c.u_max[1];
+    F.partials = partials;
+    F.partial_out = partial_out;
+    F.u = h->d_u;
+    F.u_before = h->d_uhist;
+    F.ref = h->d_ref;
+    F.pout = h->d_pout;
+    F.st = h->d_st;
+    F.res = h->d_res;
+    F.u0_trace = nullptr;
+    return F;
+}
+
+static hipEvent_t next_event(mppi_handle *h) {
+    if (h->ev_used == h->ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        h->ev.push_back(e);
+    }
+    return h->ev[h->ev_used++];
+}
+
+// rollout -> reduce -> finalize, each optionally bracketed by events (6 events per slot)
+template <typename R>
+static void launch_slot(mppi_handle *h, const KParams<R> &P, const FinalizeParams &F, hipStream_t s) {
+    const bool tm = h->timing;
+    if (tm) hipEventRecord(next_event(h), s);
+    launch_rollout<R>(P, s);
+    if (tm) hipEventRecord(next_event(h), s);
+    if (tm) hipEventRecord(next_event(h), s);
+    launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    if (tm) hipEventRecord(next_event(h), s);
+    if (tm) hipEventRecord(next_event(h), s);
+    launch_finalize(F, s);
+    if (tm) hipEventRecord(next_event(h), s);
+}
+
+static void collect_timing(mppi_handle *h) {
+    if (!h->timing) return;
+    double acc[3] = {0, 0, 0};
+    const size_t slots = h->ev_used / 6;
+    for (size_t i = 0; i < slots; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, h->ev[6 * i + 2 * j], h->ev[6 * i + 2 * j + 1]);
+            acc[j] += ms;
+        }
+    for (int j = 0; j < 3; ++j) h->last_ms[j] = slots ? (float)(acc[j] / slots) : 0.f;
+    float ms = 0;
+    hipEventElapsedTime(&ms, h->ev_step[0], h->ev_step[1]);
+    h->last_ms[3] = ms;
+}
+
+static int check_ready(mppi_handle *h, const char *who) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    if (!h->d_ref || h->n_ref < 1) FAIL(h, MPPI_ERR_STATE, "%s: ref_path has not been set", who);
+    if (h->cfg.obstacle_model != MPPI_OBSTACLE_NONE && h->n_obs > 0 && !h->d_obs)
+        FAIL(h, MPPI_ERR_STATE, "%s: obstacles not uploaded", who);
+    return MPPI_OK;
+}
+
+static void fill_stats(const mppi_handle *h, mppi_stats *stats) {
+    if (!stats) return;
+    const StepResult *r = h->h_res;
+    stats->rho = r->rho;
+    stats->eta = r->eta;
+    stats->ess = r->ess;
+    stats->idx_start = r->idx_start;
+    stats->idx_after = r->idx_after;
+    stats->path_end = r->path_end;
+    stats->rounds = r->rounds;
+    stats->iteration = r->iter;
+}
+
+template <typename R>
+static int step_impl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
+                     mppi_stats *stats, hipStream_t s) {
+    KParams<R> P = make_params<R>(h, eps);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 0, nullptr, 0);
+    h->ev_used = 0;
+    if (h->timing) hipEventRecord(h->ev_step[0], s);
+    launch_set_state<R>(P, x0, s);
+    for (int round = 0;; ++round) {
+        launch_slot<R>(h, P, F, s);
+        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+        if (h->timing) hipEventRecord(h->ev_step[1], s);
+        HIPCHECK(h, hipStreamSynchronize(s));
+        HIPCHECK(h, hipGetLastError());
+        if (h->h_res->status != STATUS_NEED_ROUND) break;
+        if (round > h->cfg.K + 1) FAIL(h, MPPI_ERR_STATE, "waypoint speculation did not converge");
+    }
+    collect_timing(h);
+    h->last_eps = eps;
+    h->last_philox = eps == nullptr;
+    h->idx = h->h_res->idx_after;
+    fill_stats(h, stats);
+    if (h->h_res->status == STATUS_PATH_END)
+        FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
+    h->iter = h->h_res->iter;
+    const double *ru = reinterpret_cast<const double *>(h->h_res + 1);
+    if (u_out) memcpy(u_out, ru, sizeof(double) * 2 * h->cfg.T);
+    if (u0_out) { u0_out[0] = h->h_res->u0[0]; u0_out[1] = h->h_res->u0[1]; }
+    return MPPI_OK;
+}
+
+extern "C" int mppi_step(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
+                         mppi_stats *stats, void *stream) {
+    int rc = check_ready(h, "mppi_step");
+    if (rc) return rc;
+    if (!x0) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step: x0 is null");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    double x[4] = {0, 0, 0, 0};
+    for (int i = 0; i < h->nx; ++i) x[i] = x0[i];
+    return h->f64 ? step_impl<double>(h, x, eps, u_out, u0_out, stats, (hipStream_t)stream)
+                  : step_impl<float>(h, x, eps, u_out, u0_out, stats, (hipStream_t)stream);
+}
+
+extern "C" int mppi_partial_len(const mppi_handle *h, int32_t *n) {
+    if (!h || !n) return MPPI_ERR_BAD_ARG;
+    *n = partial_len(h->cfg.T);
+    return MPPI_OK;
+}
+
+template <typename R>
+static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
+    KParams<R> P = make_params<R>(h, eps);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 1, partial, 0);
+    launch_set_state<R>(P, x0, s);
+    launch_rollout<R>(P, s);
+    launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    launch_finalize(F, s);
+    HIPCHECK(h, hipGetLastError());
+    h->last_eps = eps;
+    h->last_philox = eps == nullptr;
+    h->begun = true;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_step_begin(mppi_handle *h, const double *x0, const float *eps, double *partial, void *stream) {
+    int rc = check_ready(h, "mppi_step_begin");
+    if (rc) return rc;
+    if (!x0 || !partial) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_begin: null argument");
+    if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "the split step needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    double x[4] = {0, 0, 0, 0};
+    for (int i = 0; i < h->nx; ++i) x[i] = x0[i];
+    return h->f64 ? begin_impl<double>(h, x, eps, partial, (hipStream_t)stream)
+                  : begin_impl<float>(h, x, eps, partial, (hipStream_t)stream);
+}
+
+extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nranks, double *u_out, double *u0_out,
+                             mppi_stats *stats, void *stream) {
+    int rc = check_ready(h, "mppi_step_end");
+    if (rc) return rc;
+    if (!partials || nranks < 1) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end: bad partials/nranks");
+    if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end without mppi_step_begin");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    FinalizeParams F = make_finalize(h, partials, nranks, 0, nullptr, 0);
+    launch_finalize(F, s);
+    HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(h, hipStreamSynchronize(s));
+    HIPCHECK(h, hipGetLastError());
+    h->begun = false;
+    h->idx = h->h_res->idx_after;
+    fill_stats(h, stats);
+    if (h->h_res->status == STATUS_PATH_END)
+        FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
+    h->iter = h->h_res->iter;
+    const double *ru = reinterpret_cast<const double *>(h->h_res + 1);
+    if (u_out) memcpy(u_out, ru, sizeof(double) * 2 * h->cfg.T);
+    if (u0_out) { u0_out[0] = h->h_res->u0[0]; u0_out[1] = h->h_res->u0[1]; }
+    return MPPI_OK;
+}
+
+extern "C" int mppi_get_costs(mppi_handle *h, double *S) {
+    if (!h || !S) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    return download_real(h, S, h->d_S, (size_t)h->cfg.K);
+}
+
+extern "C" int mppi_get_weights(mppi_handle *h, double *w) {
+    if (!h || !w) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    if (!h->d_w) HIPCHECK(h, hipMalloc((void **)&h->d_w, sizeof(double) * h->cfg.K));
+    if (h->f64) {
+        KParams<double> P = make_params<double>(h, nullptr);
+        launch_weights<double>(P, h->h_res->rho, h->h_res->eta, h->d_w, nullptr);
+    } else {
+        KParams<float> P = make_params<float>(h, nullptr);
+        launch_weights<float>(P, h->h_res->rho, h->h_res->eta, h->d_w, nullptr);
+    }
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(w, h->d_w, sizeof(double) * h->cfg.K, hipMemcpyDeviceToHost));
+    return MPPI_OK;
+}
+
+extern "C" int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps_out, void *stream) {
+    if (!h || !eps_out || iteration < 0) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    KParams<float> P = make_params<float>(h, nullptr);
+    launch_sample(P.seed_lo, P.seed_hi, (unsigned)iteration, h->cfg.K, h->cfg.T, h->cfg.k_offset, P.chol, eps_out,
+                  (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *sampled_traj, void *stream) {
+    int rc = check_ready(h, "mppi_rollout_viz");
+    if (rc) return rc;
+    if (h->iter < 1) FAIL(h, MPPI_ERR_STATE, "mppi_rollout_viz before the first mppi_step");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    const float *eps = h->last_philox ? nullptr : h->last_eps;
+    const int T = h->cfg.T;
+    if (h->f64) {
+        KParams<double> P = make_params<double>(h, eps);
+        const double *hist = (const double *)h->d_uhist;
+        launch_viz<double>(P, hist, hist + 2 * T, h->iter - 1, optimal_traj, sampled_traj, (hipStream_t)stream);
+    } else {
+        KParams<float> P = make_params<float>(h, eps);
+        const float *hist = (const float *)h->d_uhist;
+        launch_viz<float>(P, hist, hist + 2 * T, h->iter - 1, optimal_traj, sampled_traj, (hipStream_t)stream);
+    }
+    HIPCHECK(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+template <typename R>
+static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
+    KParams<R> P = make_params<R>(h, nullptr);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 0, nullptr, 1);
+    if (u0_trace) {
+        if (h->trace_cap < n_iters) {
+            if (h->d_trace) HIPCHECK(h, hipFree(h->d_trace));
+            h->d_trace = nullptr;
+            HIPCHECK(h, hipMalloc((void **)&h->d_trace, sizeof(double) * 2 * n_iters));
+            h->trace_cap = n_iters;
+        }
+        F.u0_trace = h->d_trace - 2 * h->iter;  // the kernel indexes by the absolute iteration
+    }
+    const long long target = h->iter + n_iters;
+    h->ev_used = 0;
+    if (h->timing) hipEventRecord(h->ev_step[0], s);
+    launch_set_state<R>(P, nullptr, s);  // x0 call for the state already on the device
+    long long done = h->iter;
+    int guard = 0;
+    while (done < target) {
+        const long long todo = target - done;
+        for (long long i = 0; i < todo; ++i) launch_slot<R>(h, P, F, s);
+        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+        if (h->timing) hipEventRecord(h->ev_step[1], s);
+        HIPCHECK(h, hipStreamSynchronize(s));
+        HIPCHECK(h, hipGetLastError());
+        if (h->h_res->status == STATUS_PATH_END) break;
+        done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
+        if (++guard > h->cfg.K + 8) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
+    }
+    collect_timing(h);
+    h->last_eps = nullptr;
+    h->last_philox = true;
+    h->idx = h->h_res->idx_after;
+    fill_stats(h, stats);
+    if (h->h_res->status == STATUS_PATH_END)
+        FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
+    if (u0_trace)
+        HIPCHECK(h, hipMemcpy(u0_trace, h->d_trace, sizeof(double) * 2 * n_iters, hipMemcpyDeviceToHost));
+    h->iter = h->h_res->iter;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_trace, mppi_stats *stats,
+                                    void *stream) {
+    int rc = check_ready(h, "mppi_run_closed_loop");
+    if (rc) return rc;
+    if (n_iters < 1) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_run_closed_loop: n_iters < 1");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    return h->f64 ? closed_loop_impl<double>(h, n_iters, u0_trace, stats, (hipStream_t)stream)
+                  : closed_loop_impl<float>(h, n_iters, u0_trace, stats, (hipStream_t)stream);
+}
+
+extern "C" int mppi_enable_timing(mppi_handle *h, int32_t on) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    h->timing = on != 0;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_last_kernel_ms(mppi_handle *h, float *out4) {
+    if (!h || !out4) return MPPI_ERR_BAD_ARG;
+    memcpy(out4, h->last_ms, sizeof(h->last_ms));
+    return MPPI_OK;
+}

@@ -1,0 +1,97 @@
+// Internal interface between the C ABI (mppi_capi.hip) and the gfx950 kernels (mppi_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mppi {
+
+constexpr int MODEL_DIFF = 0, MODEL_RACE = 1;
+constexpr int OBS_NONE = 0, OBS_CIRCLE = 1, OBS_OUTLINE = 2;
+constexpr int FILTER_DIFF = 0, FILTER_RACE = 1, FILTER_NONE = 2;
+constexpr int NO_TRIGGER = 0x7fffffff;
+constexpr int STATUS_DONE = 0, STATUS_NEED_ROUND = 1, STATUS_PATH_END = 2;
+
+// Controller state that lives on the device (so closed loops need no host round trip).
+struct DevState {
+    double x0[4];      // observed state of the current iteration
+    int p;             // prev_way_point_idx at the iteration boundary
+    int c;             // waypoint index the pending rollouts start from
+    int k_start;       // first sample whose cost is not final yet (sequential mode rounds)
+    int first_k;       // atomicMin: first sample that moved the waypoint index this round
+    int round;         // speculation rounds used by the current iteration
+    int path_end;      // x0's nearest waypoint is the last one
+    int idx_start;     // c right after the x0 call
+    int pad;
+    long long iter;    // completed iterations == sampler counter
+};
+
+// What the host reads back after a step (followed by 2*T doubles: the returned u).
+struct StepResult {
+    int status, k_next, c_next, idx_start;
+    int idx_after, path_end, rounds, pad;
+    long long iter;
+    double rho, eta, ess;
+    double u0[2];
+    double x_next[4];
+};
+
+// Per-block / per-rank softmin partial: {rho, eta, eta2, W[T][2]} in doubles.
+__host__ __device__ inline int partial_len(int T) { return 3 + 2 * T; }
+
+template <typename R> struct KParams {
+    int K, T, k_offset, n_exploit;
+    int n_ref, n_obs, window, model;
+    int accumulate, sequential, obstacle_model, clamp_rollout;
+    int wrap_stage, wrap_term, use_philox, traj_per_block;
+    unsigned seed_lo, seed_hi;
+    R dt, umax0, umax1, wheel_base;
+    R beta, gamma, penalty, two_pi;
+    R sinv[4], ws[4], wt[4];
+    R shape_x[9], shape_y[9];
+    float chol[3];
+    const R *ref;      // [n_ref][4]  x, y, yaw, v
+    const R *obs;      // [n_obs][4]  x, y, threshold^2, 0
+    const R *u;        // [T][2] nominal controls
+    const float *eps;  // [K][T][2] or nullptr (Philox)
+    R *S;              // [K]
+    int *pout;         // [K] waypoint index after sample k (sequential mode)
+    DevState *st;
+};
+
+struct FinalizeParams {
+    int T, K, n_part, merge_only;
+    int filter_mode, filter_window, clamp_u, raise_at_path_end;
+    int model, sequential, plant, n_ref;
+    int window, is_f64, pad0, pad1;
+    double beta, dt, wheel_base, umax0, umax1;
+    const double *partials;  // [n_part][partial_len]
+    double *partial_out;     // merge_only: one record
+    void *u;                 // [T][2] in the kernel precision (updated in place)
+    void *u_before;          // copy of u before the update (for the viz rollouts)
+    const void *ref;         // [n_ref][4] kernel precision
+    const int *pout;
+    DevState *st;
+    StepResult *res;         // followed by 2*T doubles
+    double *u0_trace;        // nullable: closed-loop trace [iter][2]
+};
+
+struct VizParams {
+    int K, T, model, clamp_rollout;
+    int k_offset, n_exploit, use_philox, pad;
+    unsigned seed_lo, seed_hi;
+    long long iter;
+};
+
+template <typename R> void launch_set_state(const KParams<R> &P, const double *x0_or_null, hipStream_t s);
+template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s);
+template <typename R> void launch_reduce(const KParams<R> &P, double *partials, int n_blocks, hipStream_t s);
+void launch_finalize(const FinalizeParams &F, hipStream_t s);
+template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
+void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
+                   float *eps_out, hipStream_t s);
+template <typename R>
+void launch_viz(const KParams<R> &P, const R *u_before, const R *u_after_pre_shift, long long iter, float *opt,
+                float *smp, hipStream_t s);
+int reduce_blocks(int K, int traj_per_block);
+
+}  // namespace mppi

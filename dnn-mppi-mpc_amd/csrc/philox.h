@@ -1,0 +1,45 @@
+// Counter-based control-noise sampler (stage S1).  Stands in for
+// np.random.multivariate_normal (controllers/mppi_differential_drive.py:273-283): Philox4x32-10
+// keyed by the seed, counter = (global sample k, t >> 1, iteration, stream); words (r0,r1)
+// serve even t and (r2,r3) odd t; Box-Muller; 2x2 Cholesky factor.  A sample depends only
+// on (seed, iteration, k_global, t), so K can be sharded over ranks without changing the
+// draw.  oracle/philox.py restates this in NumPy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mathfn.h"
+
+namespace px {
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float uniform_open(unsigned r) {  // (2*(r>>9)+1) * 2^-24, exact in f32
+    return (float)(2u * (r >> 9) + 1u) * 5.9604644775390625e-8f;
+}
+
+// eps[k_global, t, 0..1] ~ N(0, L L^T), chol = {L00, L10, L11}
+__device__ __forceinline__ void sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned k_global, int t,
+                                       const float (&chol)[3], float &e0, float &e1) {
+    unsigned r[4];
+    philox4x32_10(k_global, (unsigned)t >> 1, iter, 0u, seed_lo, seed_hi, r);
+    const unsigned ra = (t & 1) ? r[2] : r[0], rb = (t & 1) ? r[3] : r[1];
+    const float rad = sqrtf(-2.0f * logf(uniform_open(ra)));
+    float s, c;
+    mf::sincos_turns(uniform_open(rb), s, c);
+    const float z0 = rad * c, z1 = rad * s;
+    e0 = chol[0] * z0;
+    e1 = fmaf(chol[1], z0, chol[2] * z1);
+}
+
+}  // namespace px

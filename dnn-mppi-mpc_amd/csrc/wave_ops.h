@@ -1,0 +1,86 @@
+// Wave64 cross-lane primitives for gfx950 (CDNA4).  One wavefront = 64 lanes = 4 DPP rows of 16.
+// Scans/reductions are DPP row shifts + row broadcasts (6 VALU ops, no LDS traffic).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wv {
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Returns the DPP-moved `x`; lanes the move does not write (masked rows/banks, shifted-in lanes) get `fill`.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp(float x, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                                  __builtin_bit_cast(int, x), CTRL, ROW_MASK,
+                                                                  BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int dpp(int x, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ double dpp(double x, double fill) {
+    const long long xb = __builtin_bit_cast(long long, x), fb = __builtin_bit_cast(long long, fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)fb, (int)xb, CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(fb >> 32), (int)(xb >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+struct OpAdd {
+    template <typename R> static __device__ __forceinline__ R apply(R a, R b) { return a + b; }
+    template <typename R> static __device__ __forceinline__ R identity() { return R(0); }
+};
+struct OpMin {
+    template <typename R> static __device__ __forceinline__ R apply(R a, R b) { return b < a ? b : a; }
+    template <typename R> static __device__ __forceinline__ R identity() { return R(INFINITY); }
+};
+
+// Inclusive scan over the 64 lanes (lane i <- op(x[0..i])).
+template <typename Op, typename R> __device__ __forceinline__ R scan_incl(R x) {
+    const R id = Op::template identity<R>();
+    x = Op::apply(x, dpp<DPP_ROW_SHR1>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR2>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR4>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR8>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_BCAST15, 0xA>(x, id));  // lane 15/47 -> rows 1/3
+    x = Op::apply(x, dpp<DPP_ROW_BCAST31, 0xC>(x, id));  // lane 31 -> rows 2,3
+    return x;
+}
+
+// lane i <- x[i-1], lane 0 <- carry.
+template <typename R> __device__ __forceinline__ R shift_up1(R x, R carry) { return dpp<DPP_WAVE_SHR1>(x, carry); }
+
+__device__ __forceinline__ float read_lane(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ int read_lane(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+__device__ __forceinline__ double read_lane(double x, int lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename Op, typename R> __device__ __forceinline__ R reduce(R x) {
+    return read_lane(scan_incl<Op>(x), 63);
+}
+
+__device__ __forceinline__ float shfl_xor(float x, int m) { return __shfl_xor(x, m); }
+__device__ __forceinline__ double shfl_xor(double x, int m) { return __shfl_xor(x, m); }
+
+// (d, j) -> the pair with the smallest d over the wave; ties go to the smaller j
+// (np.argmin / list.index semantics: first minimum).  Every lane gets the result.
+template <typename R> __device__ __forceinline__ void argmin_first(R &d, int &j) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const R od = shfl_xor(d, m);
+        const int oj = __shfl_xor(j, m);
+        if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+    }
+}
+
+}  // namespace wv

@@ -1,0 +1,179 @@
+"""Thin object wrapper over the C ABI handle (one engine = one controller on one GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _dev_ptr(t):
+    """Device pointer of a contiguous CUDA tensor (zero-copy hand-off to the C ABI)."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("expected a contiguous CUDA tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(getattr(stream, "cuda_stream", stream))
+
+
+class Engine:
+    """Owns an ``mppi_handle``.  All arithmetic happens in libmppi_hip.so on the GPU."""
+
+    def __init__(self, **cfg):
+        self.lib = capi.load_library()
+        c = capi.MppiConfig()
+        c.struct_size = C.sizeof(capi.MppiConfig)
+        for k, v in cfg.items():
+            if k in ("u_max", "sigma", "stage_cost_weight", "terminal_cost_weight"):
+                arr = np.asarray(v, dtype=np.float64).reshape(-1)
+                field = getattr(c, k)
+                for i in range(len(field)):
+                    field[i] = float(arr[i]) if i < arr.size else 0.0
+            else:
+                setattr(c, k, v)
+        self.cfg = c
+        self.K, self.T = int(c.K), int(c.T)
+        self.nx = 4 if c.model == capi.MODEL_RACECAR else 3
+        self._h = capi._H()
+        rc = self.lib.mppi_create(C.byref(c), C.byref(self._h))
+        if rc != capi.OK:
+            self._h = None
+            capi.check(self.lib, None, rc)
+        self.stats = capi.MppiStats()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mppi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        capi.check(self.lib, self._h, rc)
+
+    # -- configuration / state ----------------------------------------------------------------
+    def set_ref_path(self, path):
+        p = np.ascontiguousarray(path, dtype=np.float64)
+        if p.ndim != 2:
+            raise ValueError("ref_path must be 2-D")
+        self._ck(self.lib.mppi_set_ref_path(self._h, _dp(p), p.shape[0], p.shape[1]))
+
+    def set_obstacles(self, circles):
+        c = np.ascontiguousarray(circles, dtype=np.float64).reshape(-1, 3)
+        self._ck(self.lib.mppi_set_obstacles(self._h, _dp(c), c.shape[0]))
+
+    def set_u_prev(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if u.shape != (self.T, 2):
+            raise ValueError(f"u_prev must be [{self.T}, 2]")
+        self._ck(self.lib.mppi_set_u_prev(self._h, _dp(u)))
+
+    def get_u_prev(self):
+        u = np.empty((self.T, 2))
+        self._ck(self.lib.mppi_get_u_prev(self._h, _dp(u)))
+        return u
+
+    def set_waypoint_idx(self, idx):
+        self._ck(self.lib.mppi_set_waypoint_idx(self._h, int(idx)))
+
+    def get_waypoint_idx(self):
+        v = C.c_int32()
+        self._ck(self.lib.mppi_get_waypoint_idx(self._h, C.byref(v)))
+        return v.value
+
+    def set_iteration(self, it):
+        self._ck(self.lib.mppi_set_iteration(self._h, int(it)))
+
+    def set_state(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._ck(self.lib.mppi_set_state(self._h, _dp(x)))
+
+    def get_state(self):
+        x = np.empty(self.nx)
+        self._ck(self.lib.mppi_get_state(self._h, _dp(x)))
+        return x
+
+    # -- the iteration ----------------------------------------------------------------------------
+    def step(self, x0, eps=None, stream=None):
+        """One MPPI iteration.  ``eps``: CUDA float32 tensor [K,T,2] or None (on-device Philox).
+        Returns (u[T,2] shifted, u0[2], stats)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if x0.shape != (self.nx,):
+            raise ValueError(f"observed_x must have {self.nx} entries")
+        self._check_eps(eps)
+        u, u0 = np.empty((self.T, 2)), np.empty(2)
+        self._ck(self.lib.mppi_step(self._h, _dp(x0), _dev_ptr(eps), _dp(u), _dp(u0), C.byref(self.stats),
+                                    _stream_ptr(stream)))
+        return u, u0, self.stats
+
+    def _check_eps(self, eps):
+        if eps is not None:
+            import torch
+            if eps.dtype != torch.float32 or tuple(eps.shape) != (self.K, self.T, 2):
+                raise ValueError(f"eps must be float32 [{self.K}, {self.T}, 2]")
+
+    def partial_len(self):
+        n = C.c_int32()
+        self._ck(self.lib.mppi_partial_len(self._h, C.byref(n)))
+        return n.value
+
+    def step_begin(self, x0, eps, partial, stream=None):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self._check_eps(eps)
+        self._ck(self.lib.mppi_step_begin(self._h, _dp(x0), _dev_ptr(eps), _dev_ptr(partial), _stream_ptr(stream)))
+
+    def step_end(self, partials, nranks, stream=None):
+        u, u0 = np.empty((self.T, 2)), np.empty(2)
+        self._ck(self.lib.mppi_step_end(self._h, _dev_ptr(partials), int(nranks), _dp(u), _dp(u0),
+                                        C.byref(self.stats), _stream_ptr(stream)))
+        return u, u0, self.stats
+
+    def costs(self):
+        S = np.empty(self.K)
+        self._ck(self.lib.mppi_get_costs(self._h, _dp(S)))
+        return S
+
+    def weights(self):
+        w = np.empty(self.K)
+        self._ck(self.lib.mppi_get_weights(self._h, _dp(w)))
+        return w
+
+    def sample_epsilon(self, iteration, out=None, stream=None):
+        import torch
+        if out is None:
+            out = torch.empty((self.K, self.T, 2), dtype=torch.float32, device=f"cuda:{self.cfg.device}")
+        self._ck(self.lib.mppi_sample_epsilon(self._h, int(iteration), _dev_ptr(out), _stream_ptr(stream)))
+        return out
+
+    def rollout_viz(self, want_optimal=True, want_sampled=True, stream=None):
+        import torch
+        dev = f"cuda:{self.cfg.device}"
+        opt = torch.empty((self.T, self.nx), dtype=torch.float32, device=dev) if want_optimal else None
+        smp = torch.empty((self.K, self.T, self.nx), dtype=torch.float32, device=dev) if want_sampled else None
+        self._ck(self.lib.mppi_rollout_viz(self._h, _dev_ptr(opt), _dev_ptr(smp), _stream_ptr(stream)))
+        return opt, smp
+
+    def run_closed_loop(self, n_iters, trace=False, stream=None):
+        tr = np.empty((n_iters, 2)) if trace else None
+        self._ck(self.lib.mppi_run_closed_loop(self._h, int(n_iters), _dp(tr) if trace else None,
+                                               C.byref(self.stats), _stream_ptr(stream)))
+        return tr, self.stats
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.mppi_enable_timing(self._h, int(bool(on))))
+
+    def last_kernel_ms(self):
+        out = (C.c_float * 4)()
+        self._ck(self.lib.mppi_last_kernel_ms(self._h, out))
+        return {"rollout": out[0], "reduce": out[1], "finalize": out[2], "step": out[3]}

@@ -1,0 +1,203 @@
+/*
+ * mppi_hip.h -- C ABI of libmppi_hip.so, the MI355X (gfx950) MPPI rollout engine.
+ *
+ * The reference (SokhengDin/DNN-MPPI-MPC) has no FFI: its boundary for this path is the
+ * Python class surface of controllers/mppi_differential_drive*.py and
+ * controllers/mppi_race_car*.py.  This header is the C ABI placed underneath that surface
+ * (SURVEY.md section 8b); every entry point cites the reference code it stands in for.
+ * `file:line` citations are relative to the reference repository root.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative mppi_status; text via
+ *     mppi_last_error().  No exception crosses the ABI.
+ *   - "host" pointers are ordinary CPU memory; "device" pointers are HIP device memory on
+ *     the handle's GPU (e.g. torch.Tensor.data_ptr() of a contiguous CUDA tensor --
+ *     accepted zero-copy).  The caller owns every buffer it passes.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - a handle is not thread-safe: one handle per host thread / GPU.
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 1
+
+typedef enum {
+    MPPI_OK = 0,
+    MPPI_ERR_BAD_ARG = -1,    /* null pointer, bad enum, inconsistent sizes */
+    MPPI_ERR_SHAPE = -2,      /* T below the filter window, K < 1, path not set ... */
+    MPPI_ERR_NO_DEVICE = -3,  /* no HIP device / wrong architecture */
+    MPPI_ERR_HIP = -4,        /* a HIP runtime call failed */
+    MPPI_ERR_PATH_END = -5,   /* race car: nearest waypoint is the last one (mppi_race_car.py:63-65) */
+    MPPI_ERR_UNSUPPORTED = -6,/* e.g. sequential waypoint mode with K sharded over ranks */
+    MPPI_ERR_STATE = -7       /* call sequence error (step_end without step_begin ...) */
+} mppi_status;
+
+/* dynamics: controllers/mppi_differential_drive.py:182-198 / controllers/mppi_race_car.py:183-197 */
+typedef enum { MPPI_MODEL_DIFFDRIVE = 0, MPPI_MODEL_RACECAR = 1 } mppi_model;
+/* arithmetic type of the rollout/cost kernels (the noise tensor is always f32) */
+typedef enum { MPPI_PREC_F32 = 0, MPPI_PREC_F64 = 1 } mppi_precision;
+/* waypoint search state, SURVEY.md App. A.3:
+ *  SEQUENTIAL = one index threaded through all K*(T+1) cost calls in k-major order
+ *               (mppi_differential_drive.py:228,:244, update_prev_idx=True)
+ *  FROZEN     = index fixed at the nearest waypoint of x0 during rollouts
+ *               (mppi_race_car.py:143,:152, default update_prev_idx=False) */
+typedef enum { MPPI_WAYPOINT_SEQUENTIAL = 0, MPPI_WAYPOINT_FROZEN = 1 } mppi_waypoint_mode;
+/* softmin rate beta in w = exp(-beta (S - rho)):
+ *  INV_EXPLORATION 1/param_exploration (mppi_differential_drive.py:175)
+ *  INV_LAMBDA      1/param_lambda      (mppi_race_car.py:205)
+ *  LAMBDA          param_lambda        (mppi_differential_drive_torch.py:187) */
+typedef enum { MPPI_BETA_INV_EXPLORATION = 0, MPPI_BETA_INV_LAMBDA = 1, MPPI_BETA_LAMBDA = 2 } mppi_beta_mode;
+/* smoothing of the weighted noise:
+ *  DIFFDRIVE  np.convolve 'same' + edge factors incl. the repeated last-row factor
+ *             (mppi_differential_drive.py:257-271)
+ *  RACECAR    pad with first/last window/2 rows, convolve, unpad (mppi_race_car.py:211-222) */
+typedef enum { MPPI_FILTER_DIFFDRIVE = 0, MPPI_FILTER_RACECAR = 1, MPPI_FILTER_NONE = 2 } mppi_filter_mode;
+/* collision term (adds collision_penalty per colliding stage/terminal state):
+ *  CIRCLE   robot disc of radius 0.5*margin vs circles (mppi_differential_drive_obs.py:301-313)
+ *  OUTLINE  9 outline points of the (l*m) x (w*m) box vs circles (mppi_race_car_obstacle.py:241-274) */
+typedef enum { MPPI_OBSTACLE_NONE = 0, MPPI_OBSTACLE_CIRCLE = 1, MPPI_OBSTACLE_OUTLINE = 2 } mppi_obstacle_model;
+
+/*
+ * Mirrors the constructor keywords of MPPIAlgorithms (mppi_differential_drive.py:44-60,
+ * _obs.py:44-62) and MPPIRacecarController (mppi_race_car.py:10-27, _obstacle.py:11-30),
+ * plus one switch per behavioural difference between the reference's variants
+ * (SURVEY.md App. B).  Zero-initialise, set struct_size = sizeof(mppi_config).
+ */
+typedef struct {
+    int32_t struct_size;
+    int32_t device;              /* HIP device ordinal */
+    int32_t model;               /* mppi_model */
+    int32_t precision;           /* mppi_precision */
+    int32_t K;                   /* samples evaluated by THIS handle (num_samples_K / number_of_samples_K) */
+    int32_t T;                   /* horizon (num_horizons_T / horizon_step_T) */
+    int32_t K_global;            /* total samples over all ranks (0 => K) */
+    int32_t k_offset;            /* global index of this handle's first sample */
+    double delta_t;
+    double u_max[2];             /* diff: max_speed, max_omega; race: max_steer_abs, max_accel_abs */
+    double wheel_base;           /* race car only */
+    double param_exploration, param_lambda, param_alpha;
+    double sigma[4];             /* row-major 2x2 */
+    double stage_cost_weight[4]; /* diff: x,y,yaw; race: x,y,yaw,v */
+    double terminal_cost_weight[4];
+    int32_t beta_mode;           /* mppi_beta_mode */
+    int32_t accumulate_stage_cost; /* 0: S[k] = ... (mppi_differential_drive.py:124); 1: S[k] += ... (mppi_race_car.py:84) */
+    int32_t waypoint_mode;       /* mppi_waypoint_mode */
+    int32_t search_window;       /* 20 (:204), 200 (mppi_race_car.py:158), 10 (_cuda.py:201) */
+    int32_t wrap_yaw_stage;      /* (yaw + 2pi) % 2pi before the stage cost (mppi_race_car.py:141) */
+    int32_t wrap_yaw_terminal;   /* same for the terminal cost (mppi_race_car.py:150, _cuda.py:239) */
+    int32_t clamp_rollout;       /* `_g` inside the rollout (off only in mppi_differential_drive_torch.py:128) */
+    int32_t clamp_u_after_update;/* in-place clamp of u by the visualisation loop (mppi_differential_drive.py:145-149) */
+    int32_t filter_mode;         /* mppi_filter_mode */
+    int32_t filter_window;       /* 10 */
+    int32_t obstacle_model;      /* mppi_obstacle_model */
+    int32_t raise_at_path_end;   /* 1: mppi_step returns MPPI_ERR_PATH_END (mppi_race_car.py:63-65) */
+    double safety_margin;        /* diff: safety_margin_rate; race: collision_safety_margin_rate */
+    double vehicle_w, vehicle_l; /* race outline, 3.0 / 4.0 (mppi_race_car_obstacle.py:53-54) */
+    double collision_penalty;    /* 1.0e10 */
+    uint64_t seed;               /* Philox key for the on-device sampler */
+} mppi_config;
+
+/* per-iteration diagnostics (the reference only prints) */
+typedef struct {
+    double rho;           /* min_k S */
+    double eta;           /* sum_k exp(-beta (S_k - rho)) */
+    double ess;           /* effective sample size (sum w)^2 / sum w^2 */
+    int32_t idx_start;    /* waypoint index after the x0 call (mppi_differential_drive.py:96) */
+    int32_t idx_after;    /* prev_way_point_idx after the iteration */
+    int32_t path_end;     /* idx_start reached the last waypoint (:97-99) */
+    int32_t rounds;       /* speculation rounds the sequential waypoint mode needed (>= 1) */
+    int64_t iteration;    /* iterations completed by this handle */
+} mppi_stats;
+
+typedef struct mppi_handle mppi_handle;
+
+/* library level */
+int mppi_abi_version(void);
+const char *mppi_last_error(const mppi_handle *h); /* h may be NULL: last create() failure */
+int mppi_device_count(void);
+
+/* MPPIAlgorithms.__init__ / MPPIRacecarController.__init__ (mppi_differential_drive.py:44-85,
+ * mppi_race_car.py:10-52): validates, allocates the workspaces, u_prev = 0, waypoint idx = 0 */
+int mppi_create(const mppi_config *cfg, mppi_handle **out);
+int mppi_destroy(mppi_handle *h);
+
+/* `self.ref_path` (host, row-major [n, ncols], ncols = 3 (x,y,yaw) or 4 (x,y,yaw,v));
+ * re-settable like the attribute (mppi_race_car.py:267) */
+int mppi_set_ref_path(mppi_handle *h, const double *path, int32_t n, int32_t ncols);
+/* `self.obstacle_circles` (host, [m,3] = x,y,r) */
+int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m);
+/* mutable controller state: `u_prev[T,2]` and `prev_way_point_idx` / `prev_waypoints_idx`
+ * (mppi_differential_drive.py:82,:85); host pointers */
+int mppi_set_u_prev(mppi_handle *h, const double *u);
+int mppi_get_u_prev(mppi_handle *h, double *u);
+int mppi_set_waypoint_idx(mppi_handle *h, int32_t idx);
+int mppi_get_waypoint_idx(mppi_handle *h, int32_t *idx);
+
+/*
+ * One `_calc_input_control` / `_calc_control_input` (mppi_differential_drive.py:87-165,
+ * mppi_race_car.py:55-121): sample -> rollout -> cost -> softmin weight -> reduce ->
+ * filter -> update -> shift.
+ *   x0      host, nx doubles (3 diff / 4 race)                                  [observed_x]
+ *   eps     device, float[K,T,2] C-order, or NULL => Philox(seed, iteration)    [`_calc_epsilon`]
+ *   u_out   host, double[T,2]: the returned (shifted) sequence                  [`u`, :165]
+ *   u0_out  host, double[2]:  the returned first control (pre-shift u[1])       [`u[0]`, :165]
+ *   stats   host, nullable
+ * Synchronises `stream` before returning (the outputs are host memory).
+ */
+int mppi_step(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
+              mppi_stats *stats, void *stream);
+
+/*
+ * Split form for K sharded over ranks.  `begin` runs sample ->
+ * rollout -> cost -> local softmin partial and writes this rank's record
+ * {rho_g, eta_g, W_g[T,2]} (2 + 2T doubles) to `partial` (device).  The caller all-gathers
+ * the records over its communicator (RCCL); `end` merges `nranks` records (device,
+ * double[nranks, 2+2T]) and finishes the iteration identically on every rank.
+ */
+int mppi_partial_len(const mppi_handle *h, int32_t *n_doubles);
+int mppi_step_begin(mppi_handle *h, const double *x0, const float *eps, double *partial, void *stream);
+int mppi_step_end(mppi_handle *h, const double *partials, int32_t nranks, double *u_out, double *u0_out,
+                  mppi_stats *stats, void *stream);
+
+/* S[K] of the last iteration (`S`, :103) and its weights (`_compute_weight`, :167-180); host doubles */
+int mppi_get_costs(mppi_handle *h, double *S);
+int mppi_get_weights(mppi_handle *h, double *w);
+/* the noise the sampler produces for `iteration` (`_calc_epsilon`, :273-283): device float[K,T,2] */
+int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps_out, void *stream);
+/* iteration counter that keys the sampler (checkpoint / resume) */
+int mppi_set_iteration(mppi_handle *h, int64_t iteration);
+
+/*
+ * The visualisation rollouts of the last iteration (mppi_differential_drive.py:144-159):
+ * optimal_traj[T,nx] from the updated u and sampled_traj[K,T,nx] from the clamped v, both
+ * with the reference's `[t-1]` control indexing.  Device float buffers, either nullable.
+ */
+int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *sampled_traj, void *stream);
+
+/*
+ * Closed loop on the device: the plant of the reference's driver
+ * (DifferentialDrive.update_state mppi_differential_drive.py:33-40 / Vehicle.update
+ * models/vehicle.py:85-114) advances the state with the returned control after every
+ * iteration, with no host round trip.  `mppi_set_state` seeds it; `mppi_run_closed_loop`
+ * runs `n_iters` complete iterations (eps from the sampler) and synchronises once.
+ */
+int mppi_set_state(mppi_handle *h, const double *x);
+int mppi_get_state(mppi_handle *h, double *x);
+int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_trace /* host, nullable [n_iters,2] */,
+                         mppi_stats *stats, void *stream);
+
+/* duration (ms, HIP events on `stream`) of the last step's kernels:
+ * out[0] rollout+cost, out[1] softmin reduce, out[2] finalise, out[3] whole step */
+int mppi_last_kernel_ms(mppi_handle *h, float *out4);
+int mppi_enable_timing(mppi_handle *h, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H */

@@ -1,0 +1,217 @@
+"""GPU: engine-level checks at BASELINE sizes -- sampler vs its NumPy restatement, the full-size
+config against the C oracle, and size-independent properties (shard invariance, softmin shift
+invariance, permutation invariance of the weighted reduce)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import c_oracle, mppi_oracle, philox
+
+pytestmark = pytest.mark.gpu
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, float) - np.asarray(b, float)) ** 2)))
+
+
+def dd_kwargs(K, T, **over):
+    kw = dict(delta_t=0.1, ref_path=mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100),
+              max_speed=5.0, max_omega=3.14, num_samples_K=K, num_horizons_T=T, param_exploration=0.05,
+              param_lambda=1.0, param_alpha=0.2, sigma=np.array([[0.1, 0.0], [0.0, 0.01]]),
+              stage_cost_weight=np.array([5.0, 5.0, 10.0]), terminal_cost_weight=np.array([5.0, 5.0, 10.0]),
+              visualize_optimal_traj=False, visualze_sampled_trajs=False)
+    kw.update(over)
+    return kw
+
+
+def test_sampler_matches_numpy_restatement():
+    import dnn_mppi_mpc_amd as pkg
+    sigma = np.array([[0.5, 0.1], [0.1, 0.2]])
+    c = pkg.MPPIAlgorithms(**dd_kwargs(4096, 50, sigma=sigma), seed=0x1234567890ABCDEF)
+    for it in (0, 7):
+        got = c._engine.sample_epsilon(it).cpu().numpy()
+        want = philox.sample_epsilon(sigma, 0x1234567890ABCDEF, it, 4096, 50)
+        # device: fp32 log/sqrt/sincos; restatement: f64 rounded to f32 -> a few f32 ulps of |z| <= 6
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6)
+    e = got.reshape(-1, 2).astype(np.float64)
+    assert abs(e.mean(0)).max() < 5e-3
+    np.testing.assert_allclose(np.cov(e.T), sigma, atol=6e-3)
+
+
+def test_inkernel_sampler_equals_materialised_sampler():
+    """eps = NULL (Philox inside the rollout/reduce kernels) and the same numbers passed as a tensor
+    must give the same iteration."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(1024, 50)
+    a = pkg.MPPIAlgorithms(**kw, seed=99)
+    b = pkg.MPPIAlgorithms(**kw, seed=99)
+    x0 = np.array([0.3, -0.1, -0.4])
+    for it in range(3):
+        eps = b._engine.sample_epsilon(it)
+        b._calc_epsilon = lambda *aa, _e=eps, **k: _e
+        ua = a._calc_input_control(x0)[1].copy()
+        ub = b._calc_input_control(x0)[1].copy()
+        np.testing.assert_allclose(ua, ub, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(a.sample_costs(), b.sample_costs(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["dd_c2_k4096_default", "dd_c2_k4096_moderate"])
+def test_config2_full_size_against_c_oracle_and_reference(name):
+    fx = gu.load(name)
+    eps = gu.eps_of(fx)
+    o = c_oracle.DiffDriveC(**fx["meta"])
+    o.u_prev[:] = fx["u_prev_in"]
+    o.prev_way_point_idx = int(fx["idx_before"])
+    ref = o.iteration(fx["x0"], eps)
+    import dnn_mppi_mpc_amd as pkg
+    for precision, tol, stol in (("f64", 1e-8, 1e-9), ("f32", 1e-4, 3e-4)):
+        c = pkg.MPPIAlgorithms(**fx["meta"], precision=precision)
+        c.u_prev[:] = fx["u_prev_in"]
+        c.prev_way_point_idx = int(fx["idx_before"])
+        c._calc_epsilon = lambda *a, **k: eps
+        u0, u, _, _ = c._calc_input_control(fx["x0"])
+        S = c.sample_costs()
+        np.testing.assert_allclose(S, ref["S"], rtol=stol, atol=stol)
+        np.testing.assert_allclose(S, fx["S"], rtol=stol, atol=stol)
+        assert int(np.argmin(S)) == int(np.argmin(fx["S"]))
+        assert rmse(u, fx["u_returned"]) <= tol
+        assert rmse(u, ref["u_returned"]) <= tol
+        assert c.prev_way_point_idx == int(fx["idx_after"]) == ref["idx_after"]
+        assert c.last_stats.rounds >= 1
+
+
+def test_config3_obstacles_k16384_against_c_oracle():
+    """BASELINE config 3: 8 circles, K=16384, T=50 (C oracle ~50 ms)."""
+    rng = np.random.default_rng(1234)
+    circles = [[2.0, 2.0, 0.4], [3.0, 3.5, 0.4]]
+    while len(circles) < 8:
+        x, y = rng.uniform(0.5, 4.5, 2)
+        if x * x + y * y > 0.81:
+            circles.append([float(x), float(y), 0.4])
+    kw = dd_kwargs(16384, 50, ref_path=mppi_oracle.generate_point_trajectory((0.0, 0.0), (5.0, 5.0), 100),
+                   param_exploration=0.05, param_lambda=10.0, param_alpha=0.98,
+                   stage_cost_weight=10 * np.array([5.0, 6.0, 9.0]),
+                   terminal_cost_weight=10 * np.array([5.0, 6.0, 9.0]),
+                   obstacle_circles=np.array(circles), safety_margin_rate=0.8)
+    eps = philox.sample_epsilon(kw["sigma"], 77, 0, 16384, 50)
+    tt = np.arange(50)
+    u_in = np.stack([1.0 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1)
+    x0 = np.array([0.6, 0.5, 0.75])
+    o = c_oracle.DiffDriveC(**kw)
+    o.u_prev[:] = u_in
+    ref = o.iteration(x0, eps)
+    import dnn_mppi_mpc_amd as pkg
+    for precision, tol in (("f64", 1e-8), ("f32", 1e-4)):
+        c = pkg.MPPIAlgorithms(**kw, precision=precision)
+        c.u_prev[:] = u_in
+        c._calc_epsilon = lambda *a, **k: eps
+        u = c._calc_input_control(x0)[1]
+        S = c.sample_costs()
+        if precision == "f64":
+            np.testing.assert_array_equal(S > 1e9, ref["S"] > 1e9)
+            np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-9)
+        else:
+            assert np.mean((S > 1e9) != (ref["S"] > 1e9)) < 1e-3  # circle-boundary flips in f32
+        assert rmse(u, ref["u_returned"]) <= tol
+        assert c.prev_way_point_idx == ref["idx_after"]
+
+
+def test_config4_racecar_k65536_shard_against_c_oracle():
+    """BASELINE config 4's per-GPU shard (K=65536/8, T=75) against the f32 C oracle."""
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    kw = dict(ref_path=lem, horizon_step_T=75, number_of_samples_K=8192,
+              obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), collision_safety_margin_rat=1.5,
+              visualize_optimal_traj=False, visualze_sampled_trajs=False)
+    sigma = np.array([[0.5, 0.0], [0.0, 0.1]])
+    eps = philox.sample_epsilon(sigma, 5, 0, 8192, 75)
+    o = c_oracle.RaceCarC(**kw)
+    ref = o.iteration(lem[0], eps)
+    import dnn_mppi_mpc_amd as pkg
+    c = pkg.MPPIRacecarController(**kw)
+    c._calc_epsilon = lambda *a, **k: eps
+    u = c._calc_control_input(lem[0])[1]
+    S = c.sample_costs()
+    # number of colliding steps per sample: an outline point within an f32 ulp of a circle may flip
+    n_hit, n_hit_ref = np.rint(S / 1e10), np.rint(ref["S"] / 1e10)
+    assert np.mean(n_hit != n_hit_ref) < 2e-3
+    same = n_hit == n_hit_ref
+    np.testing.assert_allclose(S[same], ref["S"][same], rtol=5e-5, atol=1e-2)
+    assert rmse(u, ref["u_returned"]) <= 1e-4
+
+
+def test_shard_invariance_two_shards_one_gpu():
+    """K split over two handles (k_offset 0 / K/2) and merged through the split-step ABI gives the
+    single-handle result: exploit/explore split and Philox are keyed by the global sample index."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    base = dict(model=capi.MODEL_RACECAR, T=40, delta_t=0.05, u_max=[0.523, 2.0], wheel_base=2.5,
+                param_exploration=0.1, param_lambda=50.0, param_alpha=0.9, sigma=[0.5, 0.0, 0.0, 0.1],
+                stage_cost_weight=[50.0, 50.0, 1.0, 20.0], terminal_cost_weight=[50.0, 50.0, 1.0, 20.0],
+                beta_mode=capi.BETA_INV_LAMBDA, accumulate_stage_cost=1, waypoint_mode=capi.WAYPOINT_FROZEN,
+                search_window=200, wrap_yaw_stage=1, wrap_yaw_terminal=1, clamp_rollout=1, clamp_u_after_update=1,
+                filter_mode=capi.FILTER_RACECAR, filter_window=10, obstacle_model=capi.OBSTACLE_NONE,
+                collision_penalty=1e10, seed=4242, precision=capi.PREC_F64)
+    K = 3000
+    whole = pkg.Engine(K=K, **base)
+    parts = [pkg.Engine(K=1400, K_global=K, k_offset=0, **base), pkg.Engine(K=1600, K_global=K, k_offset=1400, **base)]
+    for e in [whole] + parts:
+        e.set_ref_path(lem)
+    x0 = lem[2].astype(np.float64)
+    n = whole.partial_len()
+    for it in range(3):
+        u_ref, u0_ref, _ = whole.step(x0)
+        gathered = torch.empty(2 * n, dtype=torch.float64, device="cuda")
+        for r, e in enumerate(parts):
+            e.step_begin(x0, None, gathered[r * n:(r + 1) * n])
+        outs = [e.step_end(gathered, 2) for e in parts]
+        for u, u0, _ in outs:
+            np.testing.assert_allclose(u, u_ref, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(u0, u0_ref, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.concatenate([e.costs() for e in parts]), whole.costs(), rtol=1e-12)
+
+
+def test_softmin_shift_and_permutation_invariance():
+    """Adding a constant to every cost leaves the update unchanged; permuting the samples (with their
+    noise rows) leaves the weighted reduce unchanged."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(2048, 50, param_exploration=0.5)
+    eps = philox.sample_epsilon(kw["sigma"], 9, 0, 2048, 50)
+    x0 = np.array([0.2, 0.0, -0.3])
+    a = pkg.MPPIAlgorithms(**kw, precision="f64", waypoint_mode="frozen")
+    a._calc_epsilon = lambda *aa, **k: eps
+    ua = a._calc_input_control(x0)[1].copy()
+    # all samples exploit (k < (1-expl)K) only for the first half: keep the permutation inside each half
+    perm = np.concatenate([np.random.default_rng(0).permutation(1024), 1024 + np.random.default_rng(1).permutation(1024)])
+    b = pkg.MPPIAlgorithms(**kw, precision="f64", waypoint_mode="frozen")
+    b._calc_epsilon = lambda *aa, **k: eps[perm]
+    ub = b._calc_input_control(x0)[1].copy()
+    np.testing.assert_allclose(ub, ua, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.sort(b.sample_costs()), np.sort(a.sample_costs()), rtol=1e-12)
+    w = a._compute_weight()
+    assert abs(w.sum() - 1.0) < 1e-12 and (w >= 0).all()
+    assert abs(a.last_stats.ess - 1.0 / np.sum(w ** 2)) < 1e-6 * a.last_stats.ess
+
+
+def test_device_closed_loop_matches_host_loop():
+    """mppi_run_closed_loop (plant + x0 call on the device, no host round trip) equals stepping from
+    the host with the oracle's plant in between."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(1024, 30)
+    a = pkg.MPPIAlgorithms(**kw, precision="f64", seed=5)
+    b = pkg.MPPIAlgorithms(**kw, precision="f64", seed=5)
+    n = 25
+    a._engine.set_state(np.zeros(3))
+    trace, st = a._engine.run_closed_loop(n, trace=True)
+    state = np.zeros(3)
+    for it in range(n):
+        u0 = b._calc_input_control(state)[0].copy()
+        np.testing.assert_allclose(trace[it], u0, rtol=1e-9, atol=1e-12)
+        state = mppi_oracle.diffdrive_plant_step(state, u0, kw["delta_t"])
+    np.testing.assert_allclose(a._engine.get_state(), state, rtol=1e-9, atol=1e-12)
+    assert st.idx_after == b.prev_way_point_idx
+    assert st.iteration == n
