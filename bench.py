@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: trajectory-steps/s of the MPPI iteration (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one closed-loop MPPI iteration (sample -> rollout -> cost -> softmin weight -> reduce ->
+filter -> shift, then the driver's plant advances the state) of BASELINE config 2: differential-drive,
+K=4096 samples x T=50 horizon, fp32, reference `__main__` parameters
+(controllers/mppi_differential_drive.py:400-410), synthetic straight-line path.  State, controls and the
+Philox-keyed noise live on the GPU; nothing crosses PCIe inside the timed region.  N > 1: one process
+per GPU (torch.distributed / RCCL), every rank evaluates K=4096 of K_global = N*4096 samples and one
+all-gather of {rho, eta, eta2, W[T,2]} per iteration merges the softmin (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured in a second pass of the same K steps with HIP
+events bracketing every kernel launch on the launch stream; `cpu_baseline` is the plain-C oracle
+(test infrastructure, oracle/mppi_oracle.c) timed on one host core, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_SAMPLES, HORIZON = 4096, 50
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def config2_kwargs(K=K_SAMPLES, T=HORIZON):
+    """BASELINE config 2 = the reference's `__main__` problem (mppi_differential_drive.py:394-419) at K=4096, T=50."""
+    x = np.linspace(0.0, 10.0, 100)
+    y = np.linspace(0.0, -5.0, 100)
+    yaw = np.arctan2(-5.0, 10.0) * np.ones(100)
+    return dict(delta_t=0.1, ref_path=np.array([x, y, yaw]).T, max_speed=5.0, max_omega=3.14, num_samples_K=K,
+                num_horizons_T=T, param_exploration=0.0001, param_lambda=1.0, param_alpha=0.2,
+                sigma=np.array([[0.1, 0.0], [0.0, 0.01]]), stage_cost_weight=np.array([5.0, 5.0, 10.0]),
+                terminal_cost_weight=np.array([5.0, 5.0, 10.0]), visualize_optimal_traj=False,
+                visualze_sampled_trajs=False)
+
+
+def cpu_baseline(budget_s=12.0):
+    """The C restatement of the reference loop on ONE host core, closed loop, eps pre-generated."""
+    from oracle import c_oracle, mppi_oracle, philox
+    kw = config2_kwargs()
+    o = c_oracle.DiffDriveC(**kw)
+    pool = [philox.sample_epsilon(kw["sigma"], 1, i, K_SAMPLES, HORIZON) for i in range(4)]
+    state = np.zeros(3)
+    o.iteration(state, pool[0])  # warm the caches
+    o = c_oracle.DiffDriveC(**kw)
+    n, spent = 0, 0.0
+    while spent < budget_s:
+        t0 = time.perf_counter()
+        out = o.iteration(state, pool[n % len(pool)])
+        spent += time.perf_counter() - t0
+        state = mppi_oracle.diffdrive_plant_step(state, out["u0_returned"], kw["delta_t"])
+        n += 1
+    return {"value": K_SAMPLES * HORIZON * n / spent, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} closed-loop iterations of the same K=4096,T=50 workload in {spent:.1f} s "
+                      "(oracle/mppi_oracle.c, scalar f64, noise pre-generated and excluded)",
+            "ms_per_step": 1e3 * spent / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+
+    import dnn_mppi_mpc_amd as pkg
+    kw = config2_kwargs(K=K_SAMPLES * world)  # K_global; each rank evaluates K_SAMPLES of them
+    ctrl = pkg.MPPIAlgorithms(**kw, precision="f32", device=local_rank, seed=2024, process_group=pg)
+    eng = ctrl._engine
+    stream = torch.cuda.current_stream()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n):
+        if world == 1:
+            eng.run_closed_loop(n, stream=stream)  # n complete iterations, one sync at the end
+        else:
+            ctrl.run_closed_loop_sharded(n)
+
+    eng.set_state(np.zeros(3))
+    run(max(1, args.warmup))
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    idx_timed = int(eng.stats.idx_after)
+
+    # second pass of the same number of steps with HIP events around every launch (same stream)
+    eng.enable_timing(True)
+    run(args.steps)
+    barrier()
+    kms = eng.last_kernel_ms()
+    eng.enable_timing(False)
+
+    # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
+    lat = None
+    if world == 1:
+        from oracle import mppi_oracle
+        state = eng.get_state()
+        ts = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            u0 = ctrl._calc_input_control(state)[0]
+            ts.append(time.perf_counter() - t1)
+            state = mppi_oracle.diffdrive_plant_step(state, u0, kw["delta_t"])
+        lat = float(np.median(ts))
+
+    if rank == 0:
+        units = K_SAMPLES * world * HORIZON
+        # algorithmic HBM bytes: 16 B per trajectory-step (two passes over the f32
+        # noise) + 8 B per trajectory (S out, S in).  The rollout launch owns one pass: 8 B/step + 4 B/traj.
+        alg_rollout = 8.0 * K_SAMPLES * HORIZON + 4.0 * K_SAMPLES
+        alg_iter = 16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES
+        t_roll = kms["rollout"] * 1e-3
+        t_all = (kms["rollout"] + kms["reduce"] + kms["finalize"]) * 1e-3
+        roof = {"bound": "hbm", "kernel": "k_rollout<float, diffdrive>",
+                "achieved": alg_rollout / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_rollout / t_roll / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "kernel_us": {k: 1e3 * v for k, v in kms.items() if k != "step"},
+                "iteration_achieved_GBs": alg_iter / t_all / 1e9,
+                "note": "noise is drawn in-kernel (Philox), so measured HBM traffic is far below the algorithmic bytes"}
+        out = {"metric": "trajectory-steps/sec (KxT/iter_time), diff-drive K=4096 T=50", "value": units * args.steps / dt,
+               "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE config 2: differential-drive analytic dynamics, K=4096 x T=50 per GPU, "
+                                      "reference __main__ parameters, closed loop with the driver's plant on the device",
+                          "K_per_gpu": K_SAMPLES, "K_global": K_SAMPLES * world, "T": HORIZON,
+                          "waypoint_mode": "sequential (reference-exact)" if world == 1 else "frozen (K-sharded)",
+                          "noise": "Philox4x32-10 in-kernel", "waypoint_idx_during_timing": idx_timed},
+               "iter_latency_us": 1e6 * dt / args.steps,
+               "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
