@@ -20,6 +20,9 @@ struct mppi_handle {
     mppi_config cfg;
     bool f64 = false;
     int nx = 3, n_ref = 0, n_obs = 0, n_blocks = 0, traj_per_block = 0;
+    bool fused = false;       // rollout + softmin partial in one launch (T <= 128)
+    int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
+    double *d_partials2 = nullptr;  // second level for large K (records merged 64:1)
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
     int *d_pout = nullptr;
     double *d_partials = nullptr, *d_w = nullptr, *d_trace = nullptr;
@@ -146,6 +149,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (tpb > 2048) tpb = 2048;
     h->traj_per_block = tpb;
     h->n_blocks = reduce_blocks(c.K, tpb);
+    h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
+    h->n_part = h->fused ? fused_blocks(c.K) : h->n_blocks;
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
     auto fail = [&](hipError_t e, const char *what) {
         g_create_error = std::string(what) + " failed: " + hipGetErrorString(e);
@@ -159,9 +164,12 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_uhist, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
     if ((e = hipMalloc(&h->d_S, r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
     if ((e = hipMalloc((void **)&h->d_pout, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
-    if ((e = hipMalloc((void **)&h->d_partials, sizeof(double) * (size_t)(h->n_blocks + 1) * partial_len(c.T))) !=
+    if ((e = hipMalloc((void **)&h->d_partials, sizeof(double) * (size_t)(h->n_part + 1) * partial_len(c.T))) !=
         hipSuccess)
         return fail(e, "hipMalloc(partials)");
+    if ((e = hipMalloc((void **)&h->d_partials2, sizeof(double) * (size_t)(h->n_part / 64 + 2) * partial_len(c.T))) !=
+        hipSuccess)
+        return fail(e, "hipMalloc(partials2)");
     if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
     if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocDefault)) != hipSuccess)
@@ -184,7 +192,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
 extern "C" int mppi_destroy(mppi_handle *h) {
     if (!h) return MPPI_OK;
     hipSetDevice(h->cfg.device);
-    void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials,
+    void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2,
                     h->d_w,   h->d_trace, h->d_st, h->d_res};
     for (void *b : bufs)
         if (b) hipFree(b);
@@ -367,15 +375,13 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     return P;
 }
 
-static FinalizeParams make_finalize(const mppi_handle *h, const double *partials, int n_part, int merge_only,
-                                    double *partial_out, int plant) {
+static FinalizeParams make_finalize(const mppi_handle *h, const double *partials, int n_part, int plant) {
     const mppi_config &c = h->cfg;
     FinalizeParams F;
     memset(&F, 0, sizeof(F));
     F.T = c.T;
     F.K = c.K;
     F.n_part = n_part;
-    F.merge_only = merge_only;
     F.filter_mode = c.filter_mode;
     F.filter_window = c.filter_window;
     F.clamp_u = c.clamp_u_after_update;
@@ -395,7 +401,6 @@ static FinalizeParams make_finalize(const mppi_handle *h, const double *partials
     F.umax0 = c.u_max[0];
     F.umax1 = c.u_max[1];
     F.partials = partials;
-    F.partial_out = partial_out;
     F.u = h->d_u;
     F.u_before = h->d_uhist;
     F.ref = h->d_ref;
@@ -415,16 +420,35 @@ static hipEvent_t next_event(mppi_handle *h) {
     return h->ev[h->ev_used++];
 }
 
-// rollout -> reduce -> finalize, each optionally bracketed by events (6 events per slot)
+// Softmin partial records of this handle's samples: rollout (+ reduce when not fused), and for large K a
+// 64:1 merge so that the finalize block never reads more than MAX_FINAL_PARTS records.
+constexpr int MAX_FINAL_PARTS = 512;
+
 template <typename R>
-static void launch_slot(mppi_handle *h, const KParams<R> &P, const FinalizeParams &F, hipStream_t s) {
+static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const double **recs,
+                         int *n_recs) {
     const bool tm = h->timing;
     if (tm) hipEventRecord(next_event(h), s);
-    launch_rollout<R>(P, s);
+    if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
+    else launch_rollout<R>(P, s);
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
-    launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    if (!h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    *recs = h->d_partials;
+    *n_recs = h->n_part;
+    if (h->n_part > MAX_FINAL_PARTS) {
+        launch_merge(h->d_partials, h->n_part, 64, h->cfg.T, beta, h->d_partials2, s);
+        *recs = h->d_partials2;
+        *n_recs = (h->n_part + 63) / 64;
+    }
     if (tm) hipEventRecord(next_event(h), s);
+}
+
+// rollout (-> reduce) -> finalize, each optionally bracketed by events (6 events per slot)
+template <typename R>
+static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
+    const bool tm = h->timing;
+    launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part);
     if (tm) hipEventRecord(next_event(h), s);
     launch_finalize(F, s);
     if (tm) hipEventRecord(next_event(h), s);
@@ -471,7 +495,7 @@ template <typename R>
 static int step_impl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
-    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 0, nullptr, 0);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
     h->ev_used = 0;
     if (h->timing) hipEventRecord(h->ev_step[0], s);
     launch_set_state<R>(P, x0, s);
@@ -519,11 +543,12 @@ extern "C" int mppi_partial_len(const mppi_handle *h, int32_t *n) {
 template <typename R>
 static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
-    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 1, partial, 0);
+    const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
+    const double *recs;
+    int n_recs;
     launch_set_state<R>(P, x0, s);
-    launch_rollout<R>(P, s);
-    launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
-    launch_finalize(F, s);
+    launch_front<R>(h, P, F.beta, s, &recs, &n_recs);
+    launch_merge(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, s);  // this rank's single record
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
@@ -552,7 +577,7 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
     if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end without mppi_step_begin");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    FinalizeParams F = make_finalize(h, partials, nranks, 0, nullptr, 0);
+    FinalizeParams F = make_finalize(h, partials, nranks, 0);
     launch_finalize(F, s);
     HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
     HIPCHECK(h, hipStreamSynchronize(s));
@@ -625,7 +650,7 @@ extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *samp
 template <typename R>
 static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, nullptr);
-    FinalizeParams F = make_finalize(h, h->d_partials, h->n_blocks, 0, nullptr, 1);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 1);
     if (u0_trace) {
         if (h->trace_cap < n_iters) {
             if (h->d_trace) HIPCHECK(h, hipFree(h->d_trace));

@@ -59,13 +59,12 @@ template <typename R> struct KParams {
 };
 
 struct FinalizeParams {
-    int T, K, n_part, merge_only;
+    int T, K, n_part, pad2;
     int filter_mode, filter_window, clamp_u, raise_at_path_end;
     int model, sequential, plant, n_ref;
     int window, is_f64, pad0, pad1;
     double beta, dt, wheel_base, umax0, umax1;
-    const double *partials;  // [n_part][partial_len]
-    double *partial_out;     // merge_only: one record
+    const double *partials;  // [n_part][partial_len], n_part <= 1024
     void *u;                 // [T][2] in the kernel precision (updated in place)
     void *u_before;          // copy of u before the update (for the viz rollouts)
     const void *ref;         // [n_ref][4] kernel precision
@@ -85,6 +84,12 @@ struct VizParams {
 template <typename R> void launch_set_state(const KParams<R> &P, const double *x0_or_null, hipStream_t s);
 template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s);
 template <typename R> void launch_reduce(const KParams<R> &P, double *partials, int n_blocks, hipStream_t s);
+// rollout + cost + per-block softmin partial in one launch (T <= 128); fused_blocks(K) records
+template <typename R> void launch_rollout_fused(const KParams<R> &P, double *partials, hipStream_t s);
+bool fused_supported(int T);
+int fused_blocks(int K);
+// merges groups of `group` records of `recs[n]` into out[ceil(n/group)]
+void launch_merge(const double *recs, int n, int group, int T, double beta, double *out, hipStream_t s);
 void launch_finalize(const FinalizeParams &F, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,

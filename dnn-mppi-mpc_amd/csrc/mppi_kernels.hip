@@ -147,31 +147,29 @@ __global__ __launch_bounds__(64) void k_set_state(const R *ref, int n_ref, int w
 // ------------------------------------------------------------------------------------------
 // S2-S4: perturb + clamp, rollout, cost.  One wave per sample, lanes over the horizon.
 // ------------------------------------------------------------------------------------------
-template <typename R, int MODEL>
-__global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-    const DevState *st = P.st;
-    if (k >= P.K || k < st->k_start) return;
-    const int c = st->c;
-    const unsigned iter = (unsigned)st->iter;
-    const R *__restrict__ ref = P.ref;
+template <typename R, int MODEL> struct Rollout {
+    const KParams<R> &P;
+    const int k, lane, c;
+    const unsigned iter;
+    const bool exploit;  // k < (1-expl)*K, :116
+    R cx, cy, cyaw, cvel;  // state carried from chunk to chunk of 64 steps (wave-uniform)
+    int p;                 // sequential mode: the threaded waypoint index
+    bool slow;             // sequential mode: some call moved the index, evolve it call by call
+    R s_acc, s_last;
+    const int n_chunk, lane_last;
 
-    // state carried from chunk to chunk of 64 steps (wave-uniform)
-    R cx = (R)st->x0[0], cy = (R)st->x0[1], cyaw = (R)st->x0[2], cvel = MODEL == MODEL_RACE ? (R)st->x0[3] : R(0);
-    const bool exploit = (k + P.k_offset) < P.n_exploit;  // k < (1-expl)*K, :116
-    int p = c;          // sequential mode: the threaded waypoint index
-    bool slow = false;  // sequential mode: some call moved the index, evolve it call by call
-    R s_acc = 0, s_last = 0;
-    const int n_chunk = (P.T + 63) >> 6;
-    const int lane_last = (P.T - 1) & 63;
+    __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState *st, int k_, int lane_)
+        : P(P_), k(k_), lane(lane_), c(st->c), iter((unsigned)st->iter),
+          exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)st->x0[0]), cy((R)st->x0[1]), cyaw((R)st->x0[2]),
+          cvel(MODEL == MODEL_RACE ? (R)st->x0[3] : R(0)), p(st->c), slow(false), s_acc(0), s_last(0),
+          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63) {}
 
-    for (int ch = 0; ch < n_chunk; ++ch) {
+    // this lane's noise for step t of sample k (S1, or the caller's tensor)
+    __device__ __forceinline__ void load_eps(int ch, float &e0, float &e1) const {
         const int t = ch * 64 + lane;
-        const bool act = t < P.T;
-        float e0 = 0.f, e1 = 0.f;
-        R u0 = 0, u1 = 0;
-        if (act) {
+        e0 = 0.f;
+        e1 = 0.f;
+        if (t < P.T) {
             if (P.use_philox) {
                 px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1);
             } else {
@@ -179,6 +177,17 @@ __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
                 e0 = e.x;
                 e1 = e.y;
             }
+        }
+    }
+
+    // steps [64 ch, 64 ch + 64) of the horizon; returns the noise it used
+    __device__ __forceinline__ void chunk(int ch, float &e0, float &e1) {
+        const R *__restrict__ ref = P.ref;
+        const int t = ch * 64 + lane;
+        const bool act = t < P.T;
+        load_eps(ch, e0, e1);
+        R u0 = 0, u1 = 0;
+        if (act) {
             u0 = P.u[2 * t];
             u1 = P.u[2 * t + 1];
         }
@@ -278,12 +287,97 @@ __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
         }
     }
 
-    R total = wv::read_lane(s_last, lane_last);
-    if (P.accumulate) total = (sizeof(R) == 4 ? s_acc : wv::reduce<wv::OpAdd>(s_acc)) + total;
-    if (lane == 0) {
-        P.S[k] = total;
-        P.pout[k] = p;
-        if (P.sequential && p != c) atomicMin(&P.st->first_k, k);
+    // S[k] once every chunk has run; also publishes the index this sample leaves behind
+    __device__ __forceinline__ R finish() {
+        R total = wv::read_lane(s_last, lane_last);
+        if (P.accumulate) total = (sizeof(R) == 4 ? s_acc : wv::reduce<wv::OpAdd>(s_acc)) + total;
+        if (lane == 0) {
+            P.S[k] = total;
+            P.pout[k] = p;
+            if (P.sequential && p != c) atomicMin(&P.st->first_k, k);
+        }
+        return total;
+    }
+};
+
+// Any horizon: S[k] only (the softmin partials come from k_reduce).
+template <typename R, int MODEL>
+__global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
+    const DevState *st = P.st;
+    if (k >= P.K || k < st->k_start) return;
+    Rollout<R, MODEL> r(P, st, k, lane);
+    for (int ch = 0; ch < r.n_chunk; ++ch) {
+        float e0, e1;
+        r.chunk(ch, e0, e1);
+    }
+    r.finish();
+}
+
+// T <= 64 NCH: rollout + cost + the block's softmin partial {rho_b, eta_b, eta2_b, W_b[T][2]} in one launch.
+// The noise stays in registers between the rollout and the weighted sum (no second pass over eps, S5-S6
+// fused into S2-S4); the block's waves meet once in LDS.  Samples below k_start (already final in an
+// earlier speculation round) re-enter with their stored cost.
+constexpr int FUSED_WAVES = 16;
+
+template <typename R, int MODEL, int NCH>
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParams<R> P,
+                                                                      double *__restrict__ partials) {
+    __shared__ R sh_S[FUSED_WAVES];
+    __shared__ R sh_acc[FUSED_WAVES][128 * NCH];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
+    const DevState *st = P.st;
+    const int k_start = st->k_start;
+    if ((blockIdx.x + 1) * FUSED_WAVES <= k_start) return;  // every sample final: the old partial stands
+    const bool valid = k < P.K;
+    float e0[NCH], e1[NCH];
+    R S_k = R(INFINITY);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
+    if (valid) {
+        Rollout<R, MODEL> r(P, st, k, lane);
+        if (k >= k_start) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (ch < r.n_chunk) r.chunk(ch, e0[ch], e1[ch]);
+            S_k = r.finish();
+        } else {
+            S_k = P.S[k];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) r.load_eps(ch, e0[ch], e1[ch]);
+        }
+    }
+    if (lane == 0) sh_S[wid] = S_k;
+    __syncthreads();
+    R rho = sh_S[0];
+#pragma unroll
+    for (int w = 1; w < FUSED_WAVES; ++w) rho = fmin(rho, sh_S[w]);
+    const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        sh_acc[wid][ch * 128 + 2 * lane] = e * (R)e0[ch];
+        sh_acc[wid][ch * 128 + 2 * lane + 1] = e * (R)e1[ch];
+    }
+    __syncthreads();
+    double *out = partials + (size_t)blockIdx.x * partial_len(P.T);
+    for (int i = threadIdx.x; i < 2 * P.T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
+        R s = 0;
+#pragma unroll
+        for (int w = 0; w < FUSED_WAVES; ++w) s += sh_acc[w][i];
+        out[3 + i] = (double)s;
+    }
+    if (threadIdx.x == 0) {
+        R eta = 0, eta2 = 0;
+        for (int w = 0; w < FUSED_WAVES; ++w) {
+            const R ew = blockIdx.x * FUSED_WAVES + w < P.K ? mf::exp_(-P.beta * (sh_S[w] - rho)) : R(0);
+            eta += ew;
+            eta2 += ew * ew;
+        }
+        out[0] = (double)rho;
+        out[1] = (double)eta;
+        out[2] = (double)eta2;
     }
 }
 
@@ -386,21 +480,97 @@ __device__ __forceinline__ void store_real(void *p, int i, int is_f64, double v)
     else ((float *)p)[i] = (float)v;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const FinalizeParams F) {
+// Block-wide merge of n softmin partial records with the rescale trick:
+// rho = min rho_b, s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  The loads of
+// W are independent of rho, laid out so that a 1024-thread block keeps ~n*2T/1024 of them in flight per
+// thread (the records come from other CUs' plain stores of a PREVIOUS launch, so ordinary loads are fine).
+// Result: W in sh_w[0, 2T); rho/eta/eta2 returned to every thread.
+constexpr int MERGE_THREADS = 1024, MERGE_GROUPS = MERGE_THREADS / 128;
+
+__device__ __forceinline__ double block_reduce_min(double v, double *sh_red, int tid) {
+    v = wv::reduce<wv::OpMin>(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh_red[tid >> 6] = v;
+    __syncthreads();
+    double r = sh_red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmin(r, sh_red[w]);
+    return r;
+}
+__device__ __forceinline__ double block_reduce_add(double v, double *sh_red, int tid) {
+    v = wv::reduce<wv::OpAdd>(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh_red[tid >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh_red[w];
+    return r;
+}
+
+__device__ __forceinline__ void merge_records(const double *__restrict__ recs, int n, int T, double beta, double *sh_w,
+                                              double *sh_s, double *sh_red, double *sh_part, double &rho,
+                                              double &eta, double &eta2) {
+    const int tid = threadIdx.x, plen = partial_len(T);
+    double m = INFINITY;
+    for (int b = tid; b < n; b += blockDim.x) m = fmin(m, recs[(size_t)b * plen]);
+    rho = block_reduce_min(m, sh_red, tid);
+    double a = 0, a2 = 0;
+    for (int b = tid; b < n; b += blockDim.x) {
+        const double *pb = recs + (size_t)b * plen;
+        const double sc = exp(-beta * (pb[0] - rho));
+        sh_s[b] = sc;
+        a += sc * pb[1];
+        a2 += sc * sc * pb[2];
+    }
+    eta = block_reduce_add(a, sh_red, tid);
+    eta2 = block_reduce_add(a2, sh_red, tid);  // (the barriers inside also publish sh_s)
+    const int col = tid & 127, grp = tid >> 7, ngrp = blockDim.x >> 7;
+    for (int i0 = 0; i0 < 2 * T; i0 += 128) {
+        const int i = i0 + col;
+        double acc = 0;
+        if (i < 2 * T) {
+#pragma unroll 8
+            for (int b = grp; b < n; b += ngrp) acc += sh_s[b] * recs[(size_t)b * plen + 3 + i];
+        }
+        sh_part[grp * 128 + col] = acc;
+        __syncthreads();
+        if (grp == 0 && i < 2 * T) {
+            double t = 0;
+            for (int g = 0; g < ngrp; ++g) t += sh_part[g * 128 + col];
+            sh_w[i] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// groups of `group` records -> one record each (large K, and the per-rank record of the split step)
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge(const double *__restrict__ recs, int n, int group, int T,
+                                                         double beta, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *sh_w = reinterpret_cast<double *>(smem);
+    double *sh_s = sh_w + 2 * T, *sh_red = sh_s + group, *sh_part = sh_red + 64;
+    const int b0 = blockIdx.x * group, nb = min(group, n - b0);
+    double rho, eta, eta2;
+    merge_records(recs + (size_t)b0 * partial_len(T), nb, T, beta, sh_w, sh_s, sh_red, sh_part, rho, eta, eta2);
+    double *o = out + (size_t)blockIdx.x * partial_len(T);
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) o[3 + i] = sh_w[i];
+    if (threadIdx.x == 0) { o[0] = rho; o[1] = eta; o[2] = eta2; }
+}
+
+__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sh_w = reinterpret_cast<double *>(smem);  // [2T] weighted noise, then filtered
     double *sh_u = sh_w + 2 * F.T;                    // [2T] updated u
     double *sh_s = sh_u + 2 * F.T;                    // [n_part] scale factors
-    double *sh_red = sh_s + F.n_part;                 // [16]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    double *sh_red = sh_s + F.n_part;                 // [64]
+    double *sh_part = sh_red + 64;                    // [MERGE_GROUPS][128]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     DevState *st = F.st;
-    const int plen = partial_len(F.T);
     StepResult *res = F.res;
     double *res_u = res ? reinterpret_cast<double *>(res + 1) : nullptr;
 
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = st->c;
-    if (!F.merge_only && F.sequential) {
+    if (F.sequential) {
         const int fk = st->first_k;
         if (fk != NO_TRIGGER) {
             const int c_new = F.pout[fk];
@@ -422,40 +592,8 @@ __global__ __launch_bounds__(256) void k_finalize(const FinalizeParams F) {
         }
     }
 
-    // --- merge softmin partials with the rescale trick --------------
-    double m = INFINITY;
-    for (int b = tid; b < F.n_part; b += blockDim.x) m = fmin(m, F.partials[(size_t)b * plen]);
-    m = wv::reduce<wv::OpMin>(m);
-    if (lane == 0) sh_red[wid] = m;
-    __syncthreads();
-    double rho = sh_red[0];
-    for (int w = 1; w < nw; ++w) rho = fmin(rho, sh_red[w]);
-    __syncthreads();
-    double eta = 0, eta2 = 0;
-    for (int b = tid; b < F.n_part; b += blockDim.x) {
-        const double *pb = F.partials + (size_t)b * plen;
-        const double s = exp(-F.beta * (pb[0] - rho));
-        sh_s[b] = s;
-        eta += s * pb[1];
-        eta2 += s * s * pb[2];
-    }
-    eta = wv::reduce<wv::OpAdd>(eta);
-    eta2 = wv::reduce<wv::OpAdd>(eta2);
-    if (lane == 0) { sh_red[4 + wid] = eta; sh_red[8 + wid] = eta2; }
-    __syncthreads();
-    eta = 0; eta2 = 0;
-    for (int w = 0; w < nw; ++w) { eta += sh_red[4 + w]; eta2 += sh_red[8 + w]; }
-    for (int i = tid; i < 2 * F.T; i += blockDim.x) {
-        double s = 0;
-        for (int b = 0; b < F.n_part; ++b) s += sh_s[b] * F.partials[(size_t)b * plen + 3 + i];
-        sh_w[i] = s;
-    }
-    __syncthreads();
-    if (F.merge_only) {  // one record per rank, to be all-gathered by the caller
-        for (int i = tid; i < 2 * F.T; i += blockDim.x) F.partial_out[3 + i] = sh_w[i];
-        if (tid == 0) { F.partial_out[0] = rho; F.partial_out[1] = eta; F.partial_out[2] = eta2; }
-        return;
-    }
+    double rho, eta, eta2;
+    merge_records(F.partials, F.n_part, F.T, F.beta, sh_w, sh_s, sh_red, sh_part, rho, eta, eta2);
     const bool path_end_abort = F.raise_at_path_end && st->path_end;  // mppi_race_car.py:63-65
 
     // --- w_eps, moving average (window W) -----------------------------------------------
@@ -661,14 +799,36 @@ template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s) {
         hipLaunchKernelGGL((k_rollout<R, MODEL_RACE>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P);
 }
 
+bool fused_supported(int T) { return T <= 128; }
+int fused_blocks(int K) { return (K + FUSED_WAVES - 1) / FUSED_WAVES; }
+
+template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, double *partials, hipStream_t s) {
+    const dim3 grid(fused_blocks(P.K)), block(64 * FUSED_WAVES);
+    if (P.T <= 64)
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, block, 0, s, P, partials);
+    else
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, block, 0, s, P, partials);
+}
+
+template <typename R> void launch_rollout_fused(const KParams<R> &P, double *partials, hipStream_t s) {
+    if (P.model == MODEL_DIFF) launch_fused_m<R, MODEL_DIFF>(P, partials, s);
+    else launch_fused_m<R, MODEL_RACE>(P, partials, s);
+}
+
 template <typename R> void launch_reduce(const KParams<R> &P, double *partials, int n_blocks, hipStream_t s) {
     const size_t shmem = sizeof(R) * ((size_t)P.traj_per_block + 16 + 4 * 128);
     hipLaunchKernelGGL(k_reduce<R>, dim3(n_blocks), dim3(256), shmem, s, P, partials);
 }
 
+void launch_merge(const double *recs, int n, int group, int T, double beta, double *out, hipStream_t s) {
+    const int blocks = (n + group - 1) / group;
+    const size_t shmem = sizeof(double) * ((size_t)2 * T + group + 64 + MERGE_GROUPS * 128);
+    hipLaunchKernelGGL(k_merge, dim3(blocks), dim3(MERGE_THREADS), shmem, s, recs, n, group, T, beta, out);
+}
+
 void launch_finalize(const FinalizeParams &F, hipStream_t s) {
-    const size_t shmem = sizeof(double) * ((size_t)4 * F.T + F.n_part + 16);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), shmem, s, F);
+    const size_t shmem = sizeof(double) * ((size_t)4 * F.T + F.n_part + 64 + MERGE_GROUPS * 128);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(MERGE_THREADS), shmem, s, F);
 }
 
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {
@@ -698,6 +858,7 @@ void launch_viz(const KParams<R> &P, const R *u_before, const R *u_upd, long lon
     template void launch_set_state<R>(const KParams<R> &, const double *, hipStream_t);                   \
     template void launch_rollout<R>(const KParams<R> &, hipStream_t);                                     \
     template void launch_reduce<R>(const KParams<R> &, double *, int, hipStream_t);                       \
+    template void launch_rollout_fused<R>(const KParams<R> &, double *, hipStream_t);                     \
     template void launch_weights<R>(const KParams<R> &, double, double, double *, hipStream_t);           \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);
 INSTANTIATE(float)

@@ -215,3 +215,40 @@ def test_device_closed_loop_matches_host_loop():
     np.testing.assert_allclose(a._engine.get_state(), state, rtol=1e-9, atol=1e-12)
     assert st.idx_after == b.prev_way_point_idx
     assert st.iteration == n
+
+
+def test_fused_and_unfused_paths_agree(monkeypatch):
+    """T <= 128 runs rollout+softmin partial in one launch; MPPI_FORCE_UNFUSED=1 selects the separate
+    k_rollout / k_reduce launches (the only path for longer horizons).  Same iteration either way."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(1000, 50, param_exploration=0.3)
+    eps = philox.sample_epsilon(kw["sigma"], 17, 0, 1000, 50)
+    x0 = np.array([1.0, -0.6, -0.2])
+    outs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("MPPI_FORCE_UNFUSED", "1")
+        c = pkg.MPPIAlgorithms(**kw, precision="f64")
+        c._calc_epsilon = lambda *a, **k: eps
+        c.prev_way_point_idx = 3
+        u = c._calc_input_control(x0)[1].copy()
+        outs.append((u, c.sample_costs(), c.prev_way_point_idx, c.last_stats.rounds))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-13)
+    assert outs[0][2:] == outs[1][2:]
+
+
+@pytest.mark.parametrize("T", [64, 65, 128, 150])
+def test_long_horizons_against_oracle(T):
+    """Horizon chunking: 64 steps per wave pass (T=65, 128: two chunks fused; T=150: three, unfused)."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(300, T, param_exploration=0.2, delta_t=0.05)
+    eps = philox.sample_epsilon(kw["sigma"], 23, 0, 300, T)
+    x0 = np.array([0.5, -0.2, -0.5])
+    ref = mppi_oracle.DiffDriveOracle(**kw).iteration(x0, eps.astype(np.float64))
+    c = pkg.MPPIAlgorithms(**kw, precision="f64")
+    c._calc_epsilon = lambda *a, **k: eps
+    u = c._calc_input_control(x0)[1]
+    np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-8, atol=1e-10)
+    assert c.prev_way_point_idx == ref["idx_after"]
