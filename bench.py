@@ -131,13 +131,16 @@ def main():
     lat = None
     if world == 1:
         from oracle import mppi_oracle
+        import contextlib
+        import io
         state = eng.get_state()
         ts = []
-        for _ in range(200):
-            t1 = time.perf_counter()
-            u0 = ctrl._calc_input_control(state)[0]
-            ts.append(time.perf_counter() - t1)
-            state = mppi_oracle.diffdrive_plant_step(state, u0, kw["delta_t"])
+        with contextlib.redirect_stdout(io.StringIO()):  # the controller prints at the path end, like the reference
+            for _ in range(200):
+                t1 = time.perf_counter()
+                u0 = ctrl._calc_input_control(state)[0]
+                ts.append(time.perf_counter() - t1)
+                state = mppi_oracle.diffdrive_plant_step(state, u0, kw["delta_t"])
         lat = float(np.median(ts))
 
     if rank == 0:

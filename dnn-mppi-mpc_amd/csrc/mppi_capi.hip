@@ -22,10 +22,11 @@ struct mppi_handle {
     int nx = 3, n_ref = 0, n_obs = 0, n_blocks = 0, traj_per_block = 0;
     bool fused = false;       // rollout + softmin partial in one launch (T <= 128)
     int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
-    double *d_partials2 = nullptr;  // second level for large K (records merged 64:1)
+    void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
     int *d_pout = nullptr;
-    double *d_partials = nullptr, *d_w = nullptr, *d_trace = nullptr;
+    void *d_partials = nullptr;     // block records in the handle's precision
+    double *d_w = nullptr, *d_trace = nullptr;
     long long trace_cap = 0;
     DevState *d_st = nullptr;
     StepResult *d_res = nullptr, *h_res = nullptr;
@@ -97,6 +98,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
              cfg->struct_size, sizeof(mppi_config));
     mppi_config c = *cfg;
     if (c.K_global == 0) c.K_global = c.K;
+    if (c.K > (1 << 20) || c.T > 2048)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "K=%d / T=%d beyond the supported 2^20 samples / 2048 steps", c.K, c.T);
     if (c.K < 1 || c.T < 1 || c.K_global < c.K || c.k_offset < 0 || c.k_offset + c.K > c.K_global)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: bad K=%d T=%d K_global=%d k_offset=%d", c.K, c.T,
              c.K_global, c.k_offset);
@@ -164,12 +167,13 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_uhist, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
     if ((e = hipMalloc(&h->d_S, r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
     if ((e = hipMalloc((void **)&h->d_pout, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
-    if ((e = hipMalloc((void **)&h->d_partials, sizeof(double) * (size_t)(h->n_part + 1) * partial_len(c.T))) !=
-        hipSuccess)
-        return fail(e, "hipMalloc(partials)");
-    if ((e = hipMalloc((void **)&h->d_partials2, sizeof(double) * (size_t)(h->n_part / 64 + 2) * partial_len(c.T))) !=
-        hipSuccess)
-        return fail(e, "hipMalloc(partials2)");
+    const size_t rec_bytes = sizeof(double) * (size_t)record_len(c.T, 8);  // enough for either precision
+    // zero-filled and padded by 256 records: the merge kernels read 256 slots unconditionally
+    const size_t n1 = (size_t)h->n_part + 256, n2 = (size_t)h->n_part / 64 + 2 + 256;
+    if ((e = hipMalloc(&h->d_partials, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMalloc(partials)");
+    if ((e = hipMalloc(&h->d_partials2, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMalloc(partials2)");
+    if ((e = hipMemset(h->d_partials, 0, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_partials2, 0, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
     if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocDefault)) != hipSuccess)
@@ -375,7 +379,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     return P;
 }
 
-static FinalizeParams make_finalize(const mppi_handle *h, const double *partials, int n_part, int plant) {
+static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, int n_part, int plant) {
     const mppi_config &c = h->cfg;
     FinalizeParams F;
     memset(&F, 0, sizeof(F));
@@ -422,10 +426,10 @@ static hipEvent_t next_event(mppi_handle *h) {
 
 // Softmin partial records of this handle's samples: rollout (+ reduce when not fused), and for large K a
 // 64:1 merge so that the finalize block never reads more than MAX_FINAL_PARTS records.
-constexpr int MAX_FINAL_PARTS = 512;
+constexpr int MAX_FINAL_PARTS = 256;  // = MERGE_MAX_RECORDS of the kernels
 
 template <typename R>
-static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const double **recs,
+static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const void **recs,
                          int *n_recs) {
     const bool tm = h->timing;
     if (tm) hipEventRecord(next_event(h), s);
@@ -437,9 +441,10 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     *recs = h->d_partials;
     *n_recs = h->n_part;
     if (h->n_part > MAX_FINAL_PARTS) {
-        launch_merge(h->d_partials, h->n_part, 64, h->cfg.T, beta, h->d_partials2, s);
+        const int group = h->n_part > 64 * MAX_FINAL_PARTS ? MAX_FINAL_PARTS : 64;
+        launch_merge<R>(h->d_partials, h->n_part, group, h->cfg.T, beta, h->d_partials2, false, s);
         *recs = h->d_partials2;
-        *n_recs = (h->n_part + 63) / 64;
+        *n_recs = (h->n_part + group - 1) / group;
     }
     if (tm) hipEventRecord(next_event(h), s);
 }
@@ -450,7 +455,7 @@ static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, h
     const bool tm = h->timing;
     launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part);
     if (tm) hipEventRecord(next_event(h), s);
-    launch_finalize(F, s);
+    launch_finalize<R>(F, false, s);
     if (tm) hipEventRecord(next_event(h), s);
 }
 
@@ -544,11 +549,11 @@ template <typename R>
 static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    const double *recs;
+    const void *recs;
     int n_recs;
     launch_set_state<R>(P, x0, s);
     launch_front<R>(h, P, F.beta, s, &recs, &n_recs);
-    launch_merge(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, s);  // this rank's single record
+    launch_merge<R>(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, true, s);  // this rank's single record (f64)
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
@@ -573,12 +578,14 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
                              mppi_stats *stats, void *stream) {
     int rc = check_ready(h, "mppi_step_end");
     if (rc) return rc;
-    if (!partials || nranks < 1) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end: bad partials/nranks");
+    if (!partials || nranks < 1 || nranks > MAX_FINAL_PARTS)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end: bad partials/nranks (1..%d)", MAX_FINAL_PARTS);
     if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end without mppi_step_begin");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     FinalizeParams F = make_finalize(h, partials, nranks, 0);
-    launch_finalize(F, s);
+    if (h->f64) launch_finalize<double>(F, true, s);
+    else launch_finalize<float>(F, true, s);
     HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
     HIPCHECK(h, hipStreamSynchronize(s));
     HIPCHECK(h, hipGetLastError());

@@ -35,8 +35,13 @@ struct StepResult {
     double x_next[4];
 };
 
-// Per-block / per-rank softmin partial: {rho, eta, eta2, W[T][2]} in doubles.
+// Per-rank softmin partial of the split step (ABI layout): {rho, eta, eta2, W[T][2]} in doubles.
 __host__ __device__ inline int partial_len(int T) { return 3 + 2 * T; }
+// Per-block record (internal layout, handle precision): {rho, eta, eta2, pad, W[2T] padded to 16 bytes}.
+__host__ __device__ inline int record_len(int T, int elem_bytes) {
+    const int vw = 16 / elem_bytes;
+    return 4 + ((2 * T + vw - 1) / vw) * vw;
+}
 
 template <typename R> struct KParams {
     int K, T, k_offset, n_exploit;
@@ -64,7 +69,7 @@ struct FinalizeParams {
     int model, sequential, plant, n_ref;
     int window, is_f64, pad0, pad1;
     double beta, dt, wheel_base, umax0, umax1;
-    const double *partials;  // [n_part][partial_len], n_part <= 1024
+    const void *partials;    // [n_part][partial_len], n_part <= 256; element type: see launch_finalize
     void *u;                 // [T][2] in the kernel precision (updated in place)
     void *u_before;          // copy of u before the update (for the viz rollouts)
     const void *ref;         // [n_ref][4] kernel precision
@@ -83,14 +88,18 @@ struct VizParams {
 
 template <typename R> void launch_set_state(const KParams<R> &P, const double *x0_or_null, hipStream_t s);
 template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s);
-template <typename R> void launch_reduce(const KParams<R> &P, double *partials, int n_blocks, hipStream_t s);
+// softmin partial records are stored in the handle's precision R (block partials) or as double (the
+// per-rank record of the split step, include/mppi_hip.h)
+template <typename R> void launch_reduce(const KParams<R> &P, void *partials, int n_blocks, hipStream_t s);
 // rollout + cost + per-block softmin partial in one launch (T <= 128); fused_blocks(K) records
-template <typename R> void launch_rollout_fused(const KParams<R> &P, double *partials, hipStream_t s);
+template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s);
 bool fused_supported(int T);
 int fused_blocks(int K);
-// merges groups of `group` records of `recs[n]` into out[ceil(n/group)]
-void launch_merge(const double *recs, int n, int group, int T, double beta, double *out, hipStream_t s);
-void launch_finalize(const FinalizeParams &F, hipStream_t s);
+// merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
+template <typename R>
+void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_f64, hipStream_t s);
+// F.partials holds n_part <= 256 records of precision R (recs_f64 false) or double
+template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f64, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
                    float *eps_out, hipStream_t s);

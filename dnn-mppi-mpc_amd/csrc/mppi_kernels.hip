@@ -22,6 +22,20 @@
 
 namespace mppi {
 
+// Diagnostic build only (make stamps): wall-clock stamps (s_memrealtime, 10 ns ticks) of block 0 / wave 0
+// at phase boundaries, written to a buffer nothing else reads.  The shipped library has no stamps.
+#ifdef MPPI_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define STAMP(n)                                                                 \
+    do {                                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[n] = wall_clock64();   \
+    } while (0)
+#else
+#define STAMP(n) \
+    do {         \
+    } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
@@ -158,10 +172,10 @@ template <typename R, int MODEL> struct Rollout {
     R s_acc, s_last;
     const int n_chunk, lane_last;
 
-    __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState *st, int k_, int lane_)
-        : P(P_), k(k_), lane(lane_), c(st->c), iter((unsigned)st->iter),
-          exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)st->x0[0]), cy((R)st->x0[1]), cyaw((R)st->x0[2]),
-          cvel(MODEL == MODEL_RACE ? (R)st->x0[3] : R(0)), p(st->c), slow(false), s_acc(0), s_last(0),
+    __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_)
+        : P(P_), k(k_), lane(lane_), c(sv.c), iter((unsigned)sv.iter),
+          exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)sv.x0[0]), cy((R)sv.x0[1]), cyaw((R)sv.x0[2]),
+          cvel(MODEL == MODEL_RACE ? (R)sv.x0[3] : R(0)), p(sv.c), slow(false), s_acc(0), s_last(0),
           n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63) {}
 
     // this lane's noise for step t of sample k (S1, or the caller's tensor)
@@ -185,7 +199,9 @@ template <typename R, int MODEL> struct Rollout {
         const R *__restrict__ ref = P.ref;
         const int t = ch * 64 + lane;
         const bool act = t < P.T;
+        STAMP(8);
         load_eps(ch, e0, e1);
+        STAMP(9);
         R u0 = 0, u1 = 0;
         if (act) {
             u0 = P.u[2 * t];
@@ -225,6 +241,7 @@ template <typename R, int MODEL> struct Rollout {
         cyaw = wv::read_lane(yaw, 63);
         if (MODEL == MODEL_RACE) cvel = wv::read_lane(vel, 63);
 
+        STAMP(10);
         // ---- waypoint index of every call in this chunk ----------------------------------
         int my_idx;
         if (!P.sequential) {
@@ -249,6 +266,7 @@ template <typename R, int MODEL> struct Rollout {
             }
         }
 
+        STAMP(11);
         // ---- stage cost of every call (only the last one survives when !accumulate) ------
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
@@ -305,9 +323,9 @@ template <typename R, int MODEL>
 __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-    const DevState *st = P.st;
-    if (k >= P.K || k < st->k_start) return;
-    Rollout<R, MODEL> r(P, st, k, lane);
+    const DevState sv = *P.st;  // one batch of scalar loads
+    if (k >= P.K || k < sv.k_start) return;
+    Rollout<R, MODEL> r(P, sv, k, lane);
     for (int ch = 0; ch < r.n_chunk; ++ch) {
         float e0, e1;
         r.chunk(ch, e0, e1);
@@ -322,22 +340,24 @@ __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
 constexpr int FUSED_WAVES = 16;
 
 template <typename R, int MODEL, int NCH>
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParams<R> P,
-                                                                      double *__restrict__ partials) {
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParams<R> P, R *__restrict__ partials) {
     __shared__ R sh_S[FUSED_WAVES];
+    __shared__ R sh_e[FUSED_WAVES];
     __shared__ R sh_acc[FUSED_WAVES][128 * NCH];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
-    const DevState *st = P.st;
-    const int k_start = st->k_start;
+    STAMP(0);
+    const DevState sv = *P.st;  // one batch of scalar loads
+    const int k_start = sv.k_start;
     if ((blockIdx.x + 1) * FUSED_WAVES <= k_start) return;  // every sample final: the old partial stands
+    STAMP(1);
     const bool valid = k < P.K;
     float e0[NCH], e1[NCH];
     R S_k = R(INFINITY);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL> r(P, st, k, lane);
+        Rollout<R, MODEL> r(P, sv, k, lane);
         if (k >= k_start) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
@@ -349,36 +369,41 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParam
             for (int ch = 0; ch < NCH; ++ch) r.load_eps(ch, e0[ch], e1[ch]);
         }
     }
+    STAMP(2);
     if (lane == 0) sh_S[wid] = S_k;
     __syncthreads();
+    STAMP(3);
     R rho = sh_S[0];
 #pragma unroll
     for (int w = 1; w < FUSED_WAVES; ++w) rho = fmin(rho, sh_S[w]);
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
+    if (lane == 0) sh_e[wid] = e;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         sh_acc[wid][ch * 128 + 2 * lane] = e * (R)e0[ch];
         sh_acc[wid][ch * 128 + 2 * lane + 1] = e * (R)e1[ch];
     }
     __syncthreads();
-    double *out = partials + (size_t)blockIdx.x * partial_len(P.T);
+    R *out = partials + (size_t)blockIdx.x * record_len(P.T, (int)sizeof(R));
     for (int i = threadIdx.x; i < 2 * P.T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
         R s = 0;
 #pragma unroll
         for (int w = 0; w < FUSED_WAVES; ++w) s += sh_acc[w][i];
-        out[3 + i] = (double)s;
+        out[4 + i] = s;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 64 * (FUSED_WAVES - 1)) {  // a lane of the last wave: the first ones carry the column sums
         R eta = 0, eta2 = 0;
+#pragma unroll
         for (int w = 0; w < FUSED_WAVES; ++w) {
-            const R ew = blockIdx.x * FUSED_WAVES + w < P.K ? mf::exp_(-P.beta * (sh_S[w] - rho)) : R(0);
+            const R ew = sh_e[w];
             eta += ew;
             eta2 += ew * ew;
         }
-        out[0] = (double)rho;
-        out[1] = (double)eta;
-        out[2] = (double)eta2;
+        out[0] = rho;
+        out[1] = eta;
+        out[2] = eta2;
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +415,7 @@ __device__ __forceinline__ bool round_unresolved(const DevState *st, int K) {
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, double *__restrict__ partials) {
+__global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevState *st = P.st;
     if (round_unresolved(st, P.K)) return;  // a repair round will recompute S first
@@ -421,13 +446,13 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, double *__re
     eta2 = wv::reduce<wv::OpAdd>(eta2);
     if (lane == 0) { sh_red[4 + wid] = eta; sh_red[8 + wid] = eta2; }
     __syncthreads();
-    double *out = partials + (size_t)blockIdx.x * partial_len(P.T);
+    R *out = partials + (size_t)blockIdx.x * record_len(P.T, (int)sizeof(R));
     if (tid == 0) {
         R a = 0, b = 0;
         for (int w = 0; w < nw; ++w) { a += sh_red[4 + w]; b += sh_red[8 + w]; }
-        out[0] = (double)rho;
-        out[1] = (double)a;
-        out[2] = (double)b;
+        out[0] = rho;
+        out[1] = a;
+        out[2] = b;
     }
 
     // W_b[t] = sum_k e_k eps[k, t]  (:132-135 with the 1/eta factored out), lanes over t
@@ -456,7 +481,7 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, double *__re
         if (tid < 128 && ch * 64 + (tid >> 1) < P.T) {
             R s = 0;
             for (int w = 0; w < nw; ++w) s += sh_acc[w * 128 + tid];
-            out[3 + ch * 128 + tid] = (double)s;
+            out[4 + ch * 128 + tid] = s;
         }
         __syncthreads();
     }
@@ -470,229 +495,374 @@ __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rh
 }
 
 // ------------------------------------------------------------------------------------------
-// S7: merge partials, moving-average filter, update, clamp, shift, plant.  One block, f64.
+// S7: merge partials, moving-average filter, update, clamp, shift, plant.  One block.
+//
+// This kernel is the serial tail of every iteration (one workgroup, nothing to overlap with), so it
+// is written for latency: 4 waves (one per SIMD, so each issues at the full rate), ONE memory round
+// trip -- every thread issues all of its loads (record heads + 32 16-byte W vectors) before the
+// first use -- and arithmetic in the handle's precision A (fp32 handles merge in fp32: DPP
+// reductions are one VALU op per step and exp is the hardware exp2; fp64 handles keep f64
+// throughout for the 1e-9 parity tests).
+//
+// Block records (written by k_rollout_fused / k_reduce / k_merge) use the INTERNAL layout
+// {rho, eta, eta2, pad, W[2T] padded to a 16-byte multiple}, so W is read as aligned 16-byte vectors;
+// the per-rank record of the split step uses the ABI layout {rho, eta, eta2, W[2T]} in doubles.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double load_real(const void *p, int i, int is_f64) {
-    return is_f64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
-}
-__device__ __forceinline__ void store_real(void *p, int i, int is_f64, double v) {
-    if (is_f64) ((double *)p)[i] = v;
-    else ((float *)p)[i] = (float)v;
+constexpr int MERGE_THREADS = 256, MERGE_GROUPS = 8, MERGE_MAXJ = 32;
+constexpr int MERGE_MAX_RECORDS = MERGE_GROUPS * MERGE_MAXJ;  // 256
+
+template <typename A> struct alignas(16) VecT { A v[16 / sizeof(A)]; };
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
+__device__ __forceinline__ float fast_div(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
+
+template <typename A> struct BlockRed {  // block-wide reductions through one LDS exchange each
+    static __device__ __forceinline__ A min1(A v, A *sh, int tid) {
+        v = wv::reduce<wv::OpMin>(v);
+        __syncthreads();
+        if ((tid & 63) == 0) sh[tid >> 6] = v;
+        __syncthreads();
+        A r = sh[0];
+#pragma unroll
+        for (int w = 1; w < MERGE_THREADS / 64; ++w) r = fmin(r, sh[w]);
+        return r;
+    }
+    static __device__ __forceinline__ void add2(A &a, A &b, A *sh, int tid) {
+        a = wv::reduce<wv::OpAdd>(a);
+        b = wv::reduce<wv::OpAdd>(b);
+        __syncthreads();
+        if ((tid & 63) == 0) { sh[tid >> 6] = a; sh[32 + (tid >> 6)] = b; }
+        __syncthreads();
+        a = 0;
+        b = 0;
+#pragma unroll
+        for (int w = 0; w < MERGE_THREADS / 64; ++w) { a += sh[w]; b += sh[32 + w]; }
+    }
+};
+
+// Merge n <= 256 records with the rescale trick: rho = min rho_b,
+// s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  Result: W in sh_w[0, 2T);
+// rho/eta/eta2 in every thread.  Records come from a PREVIOUS launch: ordinary loads are coherent.
+// INTERNAL layout: thread (vector column vc, group grp) owns records grp*rpg .. grp*rpg+rpg-1 and reads
+// each one's 16-byte W vector; absent slots re-read record n-1 with a zero scale (unconditional loads,
+// static register indices).
+template <typename A>
+__device__ __forceinline__ void merge_internal(const A *__restrict__ recs, int n, int T, A beta, A *sh_w, A *sh_s,
+                                               A *sh_red, A *sh_part, A &rho, A &eta, A &eta2) {
+    constexpr int VW = 16 / sizeof(A);
+    using V = VecT<A>;
+    const int tid = threadIdx.x;
+    const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
+    const int vc = tid & 31, grp = tid >> 5;  // thread = (16-byte column, group of 32 consecutive records)
+    const int nvc = (2 * T + VW - 1) / VW;    // 16-byte columns of W
+    const char *base = reinterpret_cast<const char *>(recs);
+    A hr = A(INFINITY), he = 0, he2 = 0;
+    if (tid < n) {
+        const A *pb = reinterpret_cast<const A *>(base + (unsigned)tid * rbytes);
+        hr = pb[0];
+        he = pb[1];
+        he2 = pb[2];
+    }
+    // Record b lives in slot b (group b / 32); slots >= n are never written by a producer and the buffers
+    // are zero-filled and padded by 256 records at creation, so every load below is unconditional and in
+    // bounds, and an absent slot contributes 0 * 0.
+    V wv_[MERGE_MAXJ];
+    auto load_tile = [&](int vt) {
+        const unsigned off0 = (unsigned)(grp * MERGE_MAXJ) * rbytes + (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+#pragma unroll
+        for (int j = 0; j < MERGE_MAXJ; ++j) wv_[j] = *reinterpret_cast<const V *>(base + (off0 + (unsigned)j * rbytes));
+    };
+    load_tile(0);
+    STAMP(24);
+    rho = BlockRed<A>::min1(hr, sh_red, tid);
+    STAMP(25);
+    const A sc = tid < n ? fast_exp(-beta * (hr - rho)) : A(0);
+    sh_s[tid] = sc;
+    eta = sc * he;
+    eta2 = sc * sc * he2;
+    BlockRed<A>::add2(eta, eta2, sh_red, tid);  // its barriers also publish sh_s
+    STAMP(26);
+    const A inv_eta = fast_div(A(1), eta);
+    const int n_tiles = (nvc + 31) / 32;
+    for (int vt = 0; vt < n_tiles; ++vt) {
+        V acc;
+#pragma unroll
+        for (int q = 0; q < VW; ++q) acc.v[q] = 0;
+#pragma unroll
+        for (int j = 0; j < MERGE_MAXJ; ++j) {
+            const A sj = sh_s[grp * MERGE_MAXJ + j];
+#pragma unroll
+            for (int q = 0; q < VW; ++q) acc.v[q] += sj * wv_[j].v[q];
+        }
+        *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
+        __syncthreads();
+        if (vt + 1 < n_tiles) load_tile(vt + 1);
+        for (int e = tid; e < 32 * VW; e += MERGE_THREADS) {
+            const int i = vt * 32 * VW + e;
+            if (i < 2 * T) {
+                A t = 0;
+#pragma unroll
+                for (int g = 0; g < MERGE_GROUPS; ++g) t += sh_part[g * 32 * VW + e];
+                sh_w[i] = t * inv_eta;  // w_eps = W / eta, :132-135
+            }
+        }
+        __syncthreads();
+    }
 }
 
-// Block-wide merge of n softmin partial records with the rescale trick:
-// rho = min rho_b, s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  The loads of
-// W are independent of rho, laid out so that a 1024-thread block keeps ~n*2T/1024 of them in flight per
-// thread (the records come from other CUs' plain stores of a PREVIOUS launch, so ordinary loads are fine).
-// Result: W in sh_w[0, 2T); rho/eta/eta2 returned to every thread.
-constexpr int MERGE_THREADS = 1024, MERGE_GROUPS = MERGE_THREADS / 128;
-
-__device__ __forceinline__ double block_reduce_min(double v, double *sh_red, int tid) {
-    v = wv::reduce<wv::OpMin>(v);
-    __syncthreads();
-    if ((tid & 63) == 0) sh_red[tid >> 6] = v;
-    __syncthreads();
-    double r = sh_red[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmin(r, sh_red[w]);
-    return r;
-}
-__device__ __forceinline__ double block_reduce_add(double v, double *sh_red, int tid) {
-    v = wv::reduce<wv::OpAdd>(v);
-    __syncthreads();
-    if ((tid & 63) == 0) sh_red[tid >> 6] = v;
-    __syncthreads();
-    double r = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh_red[w];
-    return r;
-}
-
-__device__ __forceinline__ void merge_records(const double *__restrict__ recs, int n, int T, double beta, double *sh_w,
-                                              double *sh_s, double *sh_red, double *sh_part, double &rho,
-                                              double &eta, double &eta2) {
+// ABI layout (doubles, {rho, eta, eta2, W[2T]}), n = number of ranks: few records, plain loops.
+template <typename A>
+__device__ __forceinline__ void merge_abi(const double *__restrict__ recs, int n, int T, A beta, A *sh_w, A *sh_s,
+                                          A *sh_red, A &rho, A &eta, A &eta2) {
     const int tid = threadIdx.x, plen = partial_len(T);
-    double m = INFINITY;
-    for (int b = tid; b < n; b += blockDim.x) m = fmin(m, recs[(size_t)b * plen]);
-    rho = block_reduce_min(m, sh_red, tid);
-    double a = 0, a2 = 0;
-    for (int b = tid; b < n; b += blockDim.x) {
-        const double *pb = recs + (size_t)b * plen;
-        const double sc = exp(-beta * (pb[0] - rho));
-        sh_s[b] = sc;
-        a += sc * pb[1];
-        a2 += sc * sc * pb[2];
+    A hr = A(INFINITY), he = 0, he2 = 0;
+    if (tid < n) {
+        const double *pb = recs + tid * plen;
+        hr = (A)pb[0];
+        he = (A)pb[1];
+        he2 = (A)pb[2];
     }
-    eta = block_reduce_add(a, sh_red, tid);
-    eta2 = block_reduce_add(a2, sh_red, tid);  // (the barriers inside also publish sh_s)
-    const int col = tid & 127, grp = tid >> 7, ngrp = blockDim.x >> 7;
-    for (int i0 = 0; i0 < 2 * T; i0 += 128) {
-        const int i = i0 + col;
-        double acc = 0;
-        if (i < 2 * T) {
-#pragma unroll 8
-            for (int b = grp; b < n; b += ngrp) acc += sh_s[b] * recs[(size_t)b * plen + 3 + i];
-        }
-        sh_part[grp * 128 + col] = acc;
-        __syncthreads();
-        if (grp == 0 && i < 2 * T) {
-            double t = 0;
-            for (int g = 0; g < ngrp; ++g) t += sh_part[g * 128 + col];
-            sh_w[i] = t;
-        }
-        __syncthreads();
+    rho = BlockRed<A>::min1(hr, sh_red, tid);
+    const A sc = tid < n ? fast_exp(-beta * (hr - rho)) : A(0);
+    if (tid < n) sh_s[tid] = sc;
+    eta = sc * he;
+    eta2 = sc * sc * he2;
+    BlockRed<A>::add2(eta, eta2, sh_red, tid);
+    const A inv_eta = fast_div(A(1), eta);
+    for (int i = tid; i < 2 * T; i += MERGE_THREADS) {
+        A t = 0;
+        for (int b = 0; b < n; ++b) t += sh_s[b] * (A)recs[b * plen + 3 + i];
+        sh_w[i] = t * inv_eta;  // w_eps = W / eta, :132-135
     }
+    __syncthreads();
 }
 
-// groups of `group` records -> one record each (large K, and the per-rank record of the split step)
-__global__ __launch_bounds__(MERGE_THREADS) void k_merge(const double *__restrict__ recs, int n, int group, int T,
-                                                         double beta, double *__restrict__ out) {
+// groups of `group` <= 256 internal records -> one record each: internal layout (large K) or the ABI
+// layout in doubles (the per-rank record of the split step)
+template <typename A, bool ABI_OUT>
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ recs, int n, int group, int T, A beta,
+                                                         void *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *sh_w = reinterpret_cast<double *>(smem);
-    double *sh_s = sh_w + 2 * T, *sh_red = sh_s + group, *sh_part = sh_red + 64;
+    A *sh_w = reinterpret_cast<A *>(smem);
+    A *sh_s = sh_w + 4 * T, *sh_red = sh_s + MERGE_MAX_RECORDS, *sh_part = sh_red + 64;
     const int b0 = blockIdx.x * group, nb = min(group, n - b0);
-    double rho, eta, eta2;
-    merge_records(recs + (size_t)b0 * partial_len(T), nb, T, beta, sh_w, sh_s, sh_red, sh_part, rho, eta, eta2);
-    double *o = out + (size_t)blockIdx.x * partial_len(T);
-    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) o[3 + i] = sh_w[i];
-    if (threadIdx.x == 0) { o[0] = rho; o[1] = eta; o[2] = eta2; }
+    A rho, eta, eta2;
+    merge_internal<A>(recs + (size_t)b0 * record_len(T, (int)sizeof(A)), nb, T, beta, sh_w, sh_s, sh_red, sh_part, rho,
+                      eta, eta2);
+    // merge_internal leaves W / eta; a record carries W itself
+    if (ABI_OUT) {
+        double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
+        for (int i = threadIdx.x; i < 2 * T; i += MERGE_THREADS) o[3 + i] = (double)(sh_w[i] * eta);
+        if (threadIdx.x == 0) { o[0] = (double)rho; o[1] = (double)eta; o[2] = (double)eta2; }
+    } else {
+        A *o = reinterpret_cast<A *>(out) + (size_t)blockIdx.x * record_len(T, (int)sizeof(A));
+        for (int i = threadIdx.x; i < 2 * T; i += MERGE_THREADS) o[4 + i] = sh_w[i] * eta;
+        if (threadIdx.x == 0) { o[0] = rho; o[1] = eta; o[2] = eta2; }
+    }
 }
 
+template <typename A, bool ABI_RECS>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *sh_w = reinterpret_cast<double *>(smem);  // [2T] weighted noise, then filtered
-    double *sh_u = sh_w + 2 * F.T;                    // [2T] updated u
-    double *sh_s = sh_u + 2 * F.T;                    // [n_part] scale factors
-    double *sh_red = sh_s + F.n_part;                 // [64]
-    double *sh_part = sh_red + 64;                    // [MERGE_GROUPS][128]
+    A *sh_w = reinterpret_cast<A *>(smem);  // [2T] weighted noise, then filtered
+    A *sh_u = sh_w + 2 * F.T;               // [2T] updated u
+    A *sh_s = sh_u + 2 * F.T;               // [256] scale factors
+    A *sh_red = sh_s + MERGE_MAX_RECORDS;   // [64]
+    A *sh_part = sh_red + 64;               // [MERGE_GROUPS][128]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int T = F.T, W = F.filter_window, H = W / 2;
     DevState *st = F.st;
     StepResult *res = F.res;
-    double *res_u = res ? reinterpret_cast<double *>(res + 1) : nullptr;
+    double *res_u = reinterpret_cast<double *>(res + 1);
+    A *u_dev = reinterpret_cast<A *>(F.u), *u_hist = reinterpret_cast<A *>(F.u_before);
+    const A *ref = reinterpret_cast<const A *>(F.ref);
+
+    STAMP(16);
+    // ---- loads that nothing below produces: state, this thread's u ----------------------------
+    const int fk = st->first_k, c_state = st->c, p_state = st->p, round = st->round;
+    const int idx_start = st->idx_start, path_end = st->path_end;
+    const long long iter = st->iter;
+    const double x0v[4] = {st->x0[0], st->x0[1], st->x0[2], st->x0[3]};
+    const A u_old = tid < 2 * T ? u_dev[tid] : A(0);  // elements >= 256: re-read in the loops below
 
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
-    int c_final = st->c;
-    if (F.sequential) {
-        const int fk = st->first_k;
-        if (fk != NO_TRIGGER) {
-            const int c_new = F.pout[fk];
-            if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
-                if (tid == 0) {
-                    st->k_start = fk + 1;
-                    st->c = c_new;
-                    st->first_k = NO_TRIGGER;
-                    st->round = st->round + 1;
-                    res->status = STATUS_NEED_ROUND;
-                    res->k_next = fk + 1;
-                    res->c_next = c_new;
-                    res->rounds = st->round;
-                    res->iter = st->iter;
-                }
-                return;
+    int c_final = c_state;
+    if (F.sequential && fk != NO_TRIGGER) {
+        const int c_new = F.pout[fk];
+        if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
+            if (tid == 0) {
+                st->k_start = fk + 1;
+                st->c = c_new;
+                st->first_k = NO_TRIGGER;
+                st->round = round + 1;
+                res->status = STATUS_NEED_ROUND;
+                res->k_next = fk + 1;
+                res->c_next = c_new;
+                res->rounds = round + 1;
+                res->iter = iter;
             }
-            c_final = c_new;
+            return;
         }
+        c_final = c_new;
     }
+    const int p_now = F.sequential ? c_final : p_state;  // prev_way_point_idx after this iteration
 
-    double rho, eta, eta2;
-    merge_records(F.partials, F.n_part, F.T, F.beta, sh_w, sh_s, sh_red, sh_part, rho, eta, eta2);
-    const bool path_end_abort = F.raise_at_path_end && st->path_end;  // mppi_race_car.py:63-65
+    // wave 0 prefetches the candidates of the next x0 call so that they overlap the merge
+    A cand_x = 0, cand_y = 0;
+    const int wlen_next = min(F.window, F.n_ref - p_now);
+    if (wid == 0 && F.plant && lane < wlen_next) {
+        cand_x = ref[4 * (p_now + lane)];
+        cand_y = ref[4 * (p_now + lane) + 1];
+    }
+    STAMP(17);
 
-    // --- w_eps, moving average (window W) -----------------------------------------------
-    const int T = F.T, W = F.filter_window, H = W / 2;
-    for (int i = tid; i < 2 * T; i += blockDim.x) sh_w[i] = sh_w[i] / eta;
-    __syncthreads();
+    A rho, eta, eta2;
+    if (ABI_RECS)
+        merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, sh_w, sh_s, sh_red, rho, eta,
+                     eta2);
+    else
+        merge_internal<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, sh_w, sh_s, sh_red, sh_part,
+                          rho, eta, eta2);
+    STAMP(18);
+
+    // --- moving average of w_eps (window W) ------------------------------------------------------
+    const A inv_w = fast_div(A(1), (A)W);
     for (int i = tid; i < 2 * T; i += blockDim.x) {
         const int t = i >> 1, d = i & 1;
-        double f;
+        A f;
+        // taps are read with a fully unrolled, predicated loop so the LDS reads issue back to back
+        constexpr int MAXW = 16;
         if (F.filter_mode == FILTER_DIFF) {  // np.convolve(x, ones(W)/W, 'same'): taps t-H .. t+W-1-H
-            double s = 0;
-            for (int j = t + W - 1 - H; j >= t - H; --j)
-                if (j >= 0 && j < T) s += sh_w[2 * j + d] * (1.0 / W);
-            const int n_conv = (W + 1) / 2;  // mppi_differential_drive.py:265-269
-            if (t == 0) s *= (double)W / n_conv;
-            else if (t < n_conv) s *= (double)W / (t + n_conv);
-            if (t == T - 1)
-                for (int q = 1; q < n_conv; ++q) s *= (double)W / (q + n_conv - (W % 2));
-            f = s;
-        } else if (F.filter_mode == FILTER_RACE) {  // mppi_race_car.py:211-222
-            double s = 0;
-            for (int j = t + W - 1; j >= t; --j) {  // index into the padded signal
-                const int src = j < H ? j : (j < T + H ? j - H : j - 2 * H);
-                s += sh_w[2 * src + d] * (1.0 / W);
+            A sacc = 0;
+            if (W <= MAXW) {
+#pragma unroll
+                for (int q = 0; q < MAXW; ++q) {
+                    const int j = t + W - 1 - H - q;
+                    const A val = sh_w[2 * min(max(j, 0), T - 1) + d];
+                    sacc += (q < W && j >= 0 && j < T) ? val * inv_w : A(0);
+                }
+            } else {
+                for (int j = min(T - 1, t + W - 1 - H); j >= max(0, t - H); --j) sacc += sh_w[2 * j + d] * inv_w;
             }
-            f = s;
+            const int n_conv = (W + 1) / 2;  // mppi_differential_drive.py:265-269
+            if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
+            else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
+            if (t == T - 1)
+                for (int q = 1; q < n_conv; ++q) sacc *= fast_div((A)W, (A)(q + n_conv - (W % 2)));
+            f = sacc;
+        } else if (F.filter_mode == FILTER_RACE) {  // mppi_race_car.py:211-222
+            A sacc = 0;
+            if (W <= MAXW) {
+#pragma unroll
+                for (int q = 0; q < MAXW; ++q) {
+                    const int j = t + W - 1 - q;  // index into the padded signal
+                    const int src = j < H ? j : (j < T + H ? j - H : j - 2 * H);
+                    const A val = sh_w[2 * min(max(src, 0), T - 1) + d];
+                    sacc += q < W ? val * inv_w : A(0);
+                }
+            } else {
+                for (int j = t + W - 1; j >= t; --j) {
+                    const int src = j < H ? j : (j < T + H ? j - H : j - 2 * H);
+                    sacc += sh_w[2 * src + d] * inv_w;
+                }
+            }
+            f = sacc;
         } else {
             f = sh_w[i];
         }
-        double un = load_real(F.u, i, F.is_f64) + f;  // u += w_epsilon, :141
-        if (F.clamp_u) un = mf::clamp(un, d == 0 ? F.umax0 : F.umax1);  // :145-149
+        const A uo = i == tid ? u_old : u_dev[i];
+        A un = uo + f;                                                        // u += w_epsilon, :141
+        if (F.clamp_u) un = mf::clamp(un, d == 0 ? (A)F.umax0 : (A)F.umax1);  // :145-149
         sh_u[i] = un;
     }
     __syncthreads();
-    if (path_end_abort) {
+    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated
         if (tid == 0) {
             res->status = STATUS_PATH_END;
-            res->idx_start = st->idx_start; res->idx_after = st->p; res->path_end = 1;
-            res->rounds = st->round + 1; res->iter = st->iter;
+            res->idx_start = idx_start; res->idx_after = p_state; res->path_end = 1;
+            res->rounds = round + 1; res->iter = iter;
             st->first_k = NO_TRIGGER; st->k_start = 0;
         }
         return;
     }
+    STAMP(19);
     // --- shift (:162-163); the returned sequence aliases u_prev (:165) ---------------------
     for (int i = tid; i < 2 * T; i += blockDim.x) {
         const int t = i >> 1, d = i & 1;
-        const double old = load_real(F.u, i, F.is_f64);
-        const double shifted = sh_u[2 * (t < T - 1 ? t + 1 : T - 1) + d];
-        store_real(F.u_before, i, F.is_f64, old);
-        store_real(F.u_before, 2 * T + i, F.is_f64, sh_u[i]);
-        res_u[i] = shifted;
-        store_real(F.u, i, F.is_f64, shifted);  // element i is read and written by this thread only
+        const A uo = i == tid ? u_old : u_dev[i];
+        const A shifted = sh_u[2 * (t < T - 1 ? t + 1 : T - 1) + d];
+        u_hist[i] = uo;               // u before the update and the updated, unshifted u: viz rollouts
+        u_hist[2 * T + i] = sh_u[i];
+        res_u[i] = (double)shifted;
+        u_dev[i] = shifted;  // element i is read and written by this thread only
     }
 
+    STAMP(20);
     if (wid == 0) {
-        const double u0a = sh_u[2 * (T > 1 ? 1 : 0)], u0b = sh_u[2 * (T > 1 ? 1 : 0) + 1];
-        double xn[4] = {st->x0[0], st->x0[1], st->x0[2], st->x0[3]};
+        const A u0a = sh_u[2 * (T > 1 ? 1 : 0)], u0b = sh_u[2 * (T > 1 ? 1 : 0) + 1];
+        double xn[4] = {x0v[0], x0v[1], x0v[2], x0v[3]};
         if (F.plant) {  // the driver's plant with the returned control
+            A sn_yaw, cs_yaw;
+            mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
             if (F.model == MODEL_DIFF) {  // DifferentialDrive.update_state :33-40
-                const double yaw = xn[2];
-                xn[0] += u0a * cos(yaw) * F.dt;
-                xn[1] += u0a * sin(yaw) * F.dt;
-                xn[2] += u0b * F.dt;
+                xn[0] += (double)(u0a * cs_yaw) * F.dt;
+                xn[1] += (double)(u0a * sn_yaw) * F.dt;
+                xn[2] += (double)u0b * F.dt;
             } else {  // Vehicle.update models/vehicle.py:85-114
-                const double steer = mf::clamp(u0a, F.umax0), accel = mf::clamp(u0b, F.umax1);
-                const double yaw = xn[2], v = xn[3];
-                xn[0] += v * cos(yaw) * F.dt;
-                xn[1] += v * sin(yaw) * F.dt;
-                xn[2] += v / F.wheel_base * tan(steer) * F.dt;
-                xn[3] += accel * F.dt;
+                const A steer = mf::clamp(u0a, (A)F.umax0), accel = mf::clamp(u0b, (A)F.umax1);
+                const double v = xn[3];
+                xn[0] += v * (double)cs_yaw * F.dt;
+                xn[1] += v * (double)sn_yaw * F.dt;
+                xn[2] += v / F.wheel_base * (double)mf::tan_(steer) * F.dt;
+                xn[3] += (double)accel * F.dt;
             }
         }
         if (lane == 0) {
             res->status = STATUS_DONE;
             res->k_next = 0; res->c_next = c_final;
-            res->idx_start = st->idx_start;
-            res->idx_after = F.sequential ? c_final : st->p;
-            res->path_end = st->path_end;
-            res->rounds = st->round + 1;
-            res->rho = rho; res->eta = eta; res->ess = eta * eta / eta2;
-            res->u0[0] = u0a; res->u0[1] = u0b;
+            res->idx_start = idx_start;
+            res->idx_after = p_now;
+            res->path_end = path_end;
+            res->rounds = round + 1;
+            res->rho = (double)rho; res->eta = (double)eta; res->ess = (double)(eta * eta / eta2);
+            res->u0[0] = (double)u0a; res->u0[1] = (double)u0b;
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];
-            if (F.u0_trace) { F.u0_trace[2 * st->iter] = u0a; F.u0_trace[2 * st->iter + 1] = u0b; }
-            if (F.sequential) st->p = c_final;
-            st->iter = st->iter + 1;
-            res->iter = st->iter;
-            if (F.plant) for (int q = 0; q < 4; ++q) st->x0[q] = xn[q];
-        }
-        if (F.plant) {  // next iteration's x0 call, so the next slot needs no host input
-            const int p_now = F.sequential ? c_final : st->p;
-            if (F.is_f64)
-                x0_call<double>(st, (const double *)F.ref, F.n_ref, F.window, F.sequential, lane, xn[0], xn[1], p_now);
-            else
-                x0_call<float>(st, (const float *)F.ref, F.n_ref, F.window, F.sequential, lane, xn[0], xn[1], p_now);
-        } else if (lane == 0) {
+            if (F.u0_trace) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
+            res->iter = iter + 1;
+            st->iter = iter + 1;
             st->first_k = NO_TRIGGER;
             st->k_start = 0;
+            st->round = 0;
+            if (F.sequential) st->p = c_final;
+        }
+        if (F.plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
+            A best = A(INFINITY);
+            int bj = INT_MAX;
+            const A xq = (A)xn[0], yq = (A)xn[1];
+            if (lane < wlen_next) {
+                const A dx = xq - cand_x, dy = yq - cand_y;
+                best = dx * dx + dy * dy;
+                bj = lane;
+            }
+            for (int j = lane + 64; j < wlen_next; j += 64) {  // windows wider than a wave (race car: 200)
+                const A dx = xq - ref[4 * (p_now + j)], dy = yq - ref[4 * (p_now + j) + 1];
+                const A dd = dx * dx + dy * dy;
+                if (dd < best) { best = dd; bj = j; }
+            }
+            wv::argmin_first(best, bj);
+            if (lane == 0) {
+                const int c = p_now + bj;
+                st->x0[0] = xn[0]; st->x0[1] = xn[1]; st->x0[2] = xn[2]; st->x0[3] = xn[3];
+                st->c = c;
+                st->idx_start = c;
+                st->path_end = c >= F.n_ref - 1;
+                if (!F.sequential) st->p = c;
+            }
         }
     }
+    STAMP(21);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -802,7 +972,7 @@ template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s) {
 bool fused_supported(int T) { return T <= 128; }
 int fused_blocks(int K) { return (K + FUSED_WAVES - 1) / FUSED_WAVES; }
 
-template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, double *partials, hipStream_t s) {
+template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
     const dim3 grid(fused_blocks(P.K)), block(64 * FUSED_WAVES);
     if (P.T <= 64)
         hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, block, 0, s, P, partials);
@@ -810,25 +980,36 @@ template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P,
         hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, block, 0, s, P, partials);
 }
 
-template <typename R> void launch_rollout_fused(const KParams<R> &P, double *partials, hipStream_t s) {
-    if (P.model == MODEL_DIFF) launch_fused_m<R, MODEL_DIFF>(P, partials, s);
-    else launch_fused_m<R, MODEL_RACE>(P, partials, s);
+template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s) {
+    if (P.model == MODEL_DIFF) launch_fused_m<R, MODEL_DIFF>(P, (R *)partials, s);
+    else launch_fused_m<R, MODEL_RACE>(P, (R *)partials, s);
 }
 
-template <typename R> void launch_reduce(const KParams<R> &P, double *partials, int n_blocks, hipStream_t s) {
+template <typename R> void launch_reduce(const KParams<R> &P, void *partials, int n_blocks, hipStream_t s) {
     const size_t shmem = sizeof(R) * ((size_t)P.traj_per_block + 16 + 4 * 128);
-    hipLaunchKernelGGL(k_reduce<R>, dim3(n_blocks), dim3(256), shmem, s, P, partials);
+    hipLaunchKernelGGL(k_reduce<R>, dim3(n_blocks), dim3(256), shmem, s, P, (R *)partials);
 }
 
-void launch_merge(const double *recs, int n, int group, int T, double beta, double *out, hipStream_t s) {
+static size_t merge_lds(int T, size_t elem) {
+    return elem * ((size_t)4 * T + MERGE_MAX_RECORDS + 64 + MERGE_GROUPS * 32 * (16 / elem) + 64);
+}
+
+template <typename R>
+void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_abi, hipStream_t s) {
     const int blocks = (n + group - 1) / group;
-    const size_t shmem = sizeof(double) * ((size_t)2 * T + group + 64 + MERGE_GROUPS * 128);
-    hipLaunchKernelGGL(k_merge, dim3(blocks), dim3(MERGE_THREADS), shmem, s, recs, n, group, T, beta, out);
+    if (out_abi)
+        hipLaunchKernelGGL((k_merge<R, true>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, sizeof(R)), s,
+                           (const R *)recs, n, group, T, (R)beta, out);
+    else
+        hipLaunchKernelGGL((k_merge<R, false>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, sizeof(R)), s,
+                           (const R *)recs, n, group, T, (R)beta, out);
 }
 
-void launch_finalize(const FinalizeParams &F, hipStream_t s) {
-    const size_t shmem = sizeof(double) * ((size_t)4 * F.T + F.n_part + 64 + MERGE_GROUPS * 128);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(MERGE_THREADS), shmem, s, F);
+template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
+    if (abi_recs)
+        hipLaunchKernelGGL((k_finalize<R, true>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, sizeof(R)), s, F);
+    else
+        hipLaunchKernelGGL((k_finalize<R, false>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, sizeof(R)), s, F);
 }
 
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {
@@ -854,11 +1035,19 @@ void launch_viz(const KParams<R> &P, const R *u_before, const R *u_upd, long lon
                            opt, smp);
 }
 
+#ifdef MPPI_STAMPS
+extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#endif
+
 #define INSTANTIATE(R)                                                                                    \
     template void launch_set_state<R>(const KParams<R> &, const double *, hipStream_t);                   \
     template void launch_rollout<R>(const KParams<R> &, hipStream_t);                                     \
-    template void launch_reduce<R>(const KParams<R> &, double *, int, hipStream_t);                       \
-    template void launch_rollout_fused<R>(const KParams<R> &, double *, hipStream_t);                     \
+    template void launch_reduce<R>(const KParams<R> &, void *, int, hipStream_t);                         \
+    template void launch_rollout_fused<R>(const KParams<R> &, void *, hipStream_t);                       \
+    template void launch_merge<R>(const void *, int, int, int, double, void *, bool, hipStream_t);        \
+    template void launch_finalize<R>(const FinalizeParams &, bool, hipStream_t);                          \
     template void launch_weights<R>(const KParams<R> &, double, double, double *, hipStream_t);           \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);
 INSTANTIATE(float)

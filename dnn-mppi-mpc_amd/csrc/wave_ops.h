@@ -39,6 +39,10 @@ struct OpMin {
     template <typename R> static __device__ __forceinline__ R apply(R a, R b) { return b < a ? b : a; }
     template <typename R> static __device__ __forceinline__ R identity() { return R(INFINITY); }
 };
+struct OpMinInt {
+    static __device__ __forceinline__ int apply(int a, int b) { return b < a ? b : a; }
+    template <typename R> static __device__ __forceinline__ int identity() { return 0x7fffffff; }
+};
 
 // Inclusive scan over the 64 lanes (lane i <- op(x[0..i])).
 template <typename Op, typename R> __device__ __forceinline__ R scan_incl(R x) {
@@ -74,13 +78,11 @@ __device__ __forceinline__ double shfl_xor(double x, int m) { return __shfl_xor(
 
 // (d, j) -> the pair with the smallest d over the wave; ties go to the smaller j
 // (np.argmin / list.index semantics: first minimum).  Every lane gets the result.
+// Two DPP reductions (min of d, then min of j among the lanes that hold it): 12 VALU ops, no LDS traffic.
 template <typename R> __device__ __forceinline__ void argmin_first(R &d, int &j) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const R od = shfl_xor(d, m);
-        const int oj = __shfl_xor(j, m);
-        if (od < d || (od == d && oj < j)) { d = od; j = oj; }
-    }
+    const R m = reduce<OpMin>(d);
+    j = reduce<OpMinInt>(d == m ? j : 0x7fffffff);
+    d = m;
 }
 
 }  // namespace wv

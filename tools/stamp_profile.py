@@ -1,0 +1,41 @@
+"""Diagnostic: where does one iteration spend its time?  Uses lib/libmppi_hip_stamps.so (make stamps),
+a build with s_memrealtime stamps of block 0 at phase boundaries.  Not part of the product or the tests."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+import dnn_mppi_mpc_amd as pkg  # noqa: E402
+from dnn_mppi_mpc_amd import _capi  # noqa: E402
+
+_capi.LIB_PATH = os.path.join(ROOT, "dnn-mppi-mpc_amd", "lib", "libmppi_hip_stamps.so")
+from bench import config2_kwargs  # noqa: E402
+
+ctrl = pkg.MPPIAlgorithms(**config2_kwargs(), precision=sys.argv[1] if len(sys.argv) > 1 else "f32", seed=1)
+eng = ctrl._engine
+eng.set_state(np.zeros(3))
+eng.run_closed_loop(300)
+lib = eng.lib
+names = {0: "roll:start", 1: "roll:state loaded", 8: "roll:chunk start", 9: "roll:eps ready", 10: "roll:dynamics done",
+         11: "roll:index done", 2: "roll:S done", 3: "roll:block sync", 4: "roll:end", 16: "fin:start",
+         17: "fin:prefetch issued", 24: "fin:merge loads issued", 25: "fin:min done", 26: "fin:eta done",
+         18: "fin:merge done", 19: "fin:filter done", 20: "fin:shift done", 21: "fin:end"}
+acc = {}
+N = 50
+for _ in range(N):
+    eng.run_closed_loop(1)
+    buf = (C.c_ulonglong * 64)()
+    lib.mppi_debug_stamps(buf, 64)
+    for grp in ((0, 1, 8, 9, 10, 11, 2, 3, 4), (16, 17, 24, 25, 26, 18, 19, 20, 21)):
+        base = buf[grp[0]]
+        for g in grp:
+            acc.setdefault(g, []).append((buf[g] - base) * 10.0)  # ns (100 MHz)
+for grp in ((0, 1, 8, 9, 10, 11, 2, 3, 4), (16, 17, 24, 25, 26, 18, 19, 20, 21)):
+    for g in grp:
+        print(f"{names[g]:28s} +{np.median(acc[g]):8.0f} ns")
+    print()
