@@ -68,6 +68,8 @@ PROTOTYPES = {
     "mppi_partial_len": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_step_begin": (C.c_int, [_H, _D, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_step_end": (C.c_int, [_H, C.c_void_p, C.c_int32, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
+    "mppi_step_end_async": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mppi_sync_result": (C.c_int, [_H, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_get_costs": (C.c_int, [_H, _D]),
     "mppi_get_weights": (C.c_int, [_H, _D]),
     "mppi_sample_epsilon": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -18,6 +18,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _capi as capi
+from .distributed import exchange_partials, shard_range
 from .engine import Engine
 
 
@@ -57,9 +58,8 @@ class _ControllerBase:
             self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         K = cfg["K"]
         if self._world > 1:  # contiguous K/world shard per rank, SURVEY.md section 8e
-            base, rem = divmod(K, self._world)
-            k_local = base + (1 if self._rank < rem else 0)
-            cfg.update(K=k_local, K_global=K, k_offset=self._rank * base + min(self._rank, rem))
+            k0, k_local = shard_range(K, self._rank, self._world)
+            cfg.update(K=k_local, K_global=K, k_offset=k0)
         self._engine = Engine(**cfg)
         self._ref_path = None
         self.ref_path = ref_path
@@ -163,20 +163,46 @@ class _ControllerBase:
         self._last_eps = eps  # keep the tensor alive for the viz rollouts
         return st
 
-    def _sharded_step(self, x0, eps):
-        """K sharded over the ranks of ``process_group``: one all-gather of {rho, eta, eta2, W[T,2]} per
-        iteration (RCCL on GPUs), every rank finishes the iteration identically."""
+    def _exchange_buffers(self):
         import torch
-        import torch.distributed as dist
-        dev = f"cuda:{self._engine.cfg.device}"
-        n = self._engine.partial_len()
         if self._partial is None:
+            dev = f"cuda:{self._engine.cfg.device}"
+            n = self._engine.partial_len()
             self._partial = torch.empty(n, dtype=torch.float64, device=dev)
             self._gathered = torch.empty(self._world * n, dtype=torch.float64, device=dev)
+        return self._partial, self._gathered
+
+    def _all_gather_partials(self):
+        """The one exchange step of an iteration (RCCL all-gather of 3+2T doubles per rank)."""
+        part, gath = self._exchange_buffers()
+        return exchange_partials(part, self._world, self._pg, out=gath)
+
+    def _sharded_step(self, x0, eps):
+        """K sharded over the ranks of ``process_group``: one all-gather per iteration, every rank finishes
+        the iteration identically."""
+        import torch
+        part, _ = self._exchange_buffers()
         stream = torch.cuda.current_stream()
-        self._engine.step_begin(x0, eps, self._partial, stream)
-        dist.all_gather_into_tensor(self._gathered, self._partial, group=self._pg)
-        return self._engine.step_end(self._gathered, self._world, stream)
+        self._engine.step_begin(x0, eps, part, stream)
+        gath = self._all_gather_partials()
+        return self._engine.step_end(gath, self._world, stream)
+
+    def run_closed_loop_sharded(self, n_iters):
+        """n iterations with the driver's plant on the device and K sharded over the ranks; nothing but
+        the all-gather leaves the GPU, one synchronisation at the end."""
+        import torch
+        part, _ = self._exchange_buffers()
+        stream = torch.cuda.current_stream()
+        for _ in range(int(n_iters)):
+            self._engine.step_begin(None, None, part, stream)
+            gath = self._all_gather_partials()
+            self._engine.step_end_async(gath, self._world, stream)
+        u, u0, st = self._engine.sync_result(stream)
+        self._u_host[...] = u
+        self._u_dev_copy[...] = u
+        self._idx_host = self._idx_dev = int(st.idx_after)
+        self.last_stats = st
+        return st
 
     def _viz(self, want_opt, want_smp):
         nx = self.dim_x

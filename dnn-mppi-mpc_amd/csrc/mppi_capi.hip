@@ -32,7 +32,7 @@ struct mppi_handle {
     StepResult *d_res = nullptr, *h_res = nullptr;
     size_t res_bytes = 0;
     const float *last_eps = nullptr;
-    bool last_philox = true, begun = false, timing = false;
+    bool last_philox = true, begun = false, timing = false, dev_loop_primed = false;
     long long iter = 0;
     int idx = 0;
     std::vector<hipEvent_t> ev;  // pairs around the rollout / reduce / finalize kernels
@@ -297,6 +297,7 @@ extern "C" int mppi_set_state(mppi_handle *h, const double *x) {
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
     HIPCHECK(h, hipMemcpy(h->d_st->x0, v, sizeof(v), hipMemcpyHostToDevice));
+    h->dev_loop_primed = false;
     return MPPI_OK;
 }
 
@@ -514,6 +515,7 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
         if (round > h->cfg.K + 1) FAIL(h, MPPI_ERR_STATE, "waypoint speculation did not converge");
     }
     collect_timing(h);
+    h->dev_loop_primed = false;
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
     h->idx = h->h_res->idx_after;
@@ -551,7 +553,9 @@ static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double
     const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
     const void *recs;
     int n_recs;
-    launch_set_state<R>(P, x0, s);
+    // closed loop on the device: the previous end_async already made the x0 call for the new state
+    if (x0 || !h->dev_loop_primed) launch_set_state<R>(P, x0, s);
+    h->dev_loop_primed = x0 == nullptr;
     launch_front<R>(h, P, F.beta, s, &recs, &n_recs);
     launch_merge<R>(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, true, s);  // this rank's single record (f64)
     HIPCHECK(h, hipGetLastError());
@@ -564,14 +568,15 @@ static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double
 extern "C" int mppi_step_begin(mppi_handle *h, const double *x0, const float *eps, double *partial, void *stream) {
     int rc = check_ready(h, "mppi_step_begin");
     if (rc) return rc;
-    if (!x0 || !partial) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_begin: null argument");
+    if (!partial) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_begin: null argument");
     if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
         FAIL(h, MPPI_ERR_UNSUPPORTED, "the split step needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     double x[4] = {0, 0, 0, 0};
-    for (int i = 0; i < h->nx; ++i) x[i] = x0[i];
-    return h->f64 ? begin_impl<double>(h, x, eps, partial, (hipStream_t)stream)
-                  : begin_impl<float>(h, x, eps, partial, (hipStream_t)stream);
+    if (x0)
+        for (int i = 0; i < h->nx; ++i) x[i] = x0[i];
+    return h->f64 ? begin_impl<double>(h, x0 ? x : nullptr, eps, partial, (hipStream_t)stream)
+                  : begin_impl<float>(h, x0 ? x : nullptr, eps, partial, (hipStream_t)stream);
 }
 
 extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nranks, double *u_out, double *u0_out,
@@ -590,6 +595,39 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
     HIPCHECK(h, hipStreamSynchronize(s));
     HIPCHECK(h, hipGetLastError());
     h->begun = false;
+    h->dev_loop_primed = false;  // no plant ran: the next device-state step makes its own x0 call
+    h->idx = h->h_res->idx_after;
+    fill_stats(h, stats);
+    if (h->h_res->status == STATUS_PATH_END)
+        FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
+    h->iter = h->h_res->iter;
+    const double *ru = reinterpret_cast<const double *>(h->h_res + 1);
+    if (u_out) memcpy(u_out, ru, sizeof(double) * 2 * h->cfg.T);
+    if (u0_out) { u0_out[0] = h->h_res->u0[0]; u0_out[1] = h->h_res->u0[1]; }
+    return MPPI_OK;
+}
+
+extern "C" int mppi_step_end_async(mppi_handle *h, const double *partials, int32_t nranks, void *stream) {
+    int rc = check_ready(h, "mppi_step_end_async");
+    if (rc) return rc;
+    if (!partials || nranks < 1 || nranks > MAX_FINAL_PARTS)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end_async: bad partials/nranks (1..%d)", MAX_FINAL_PARTS);
+    if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end_async without mppi_step_begin");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    FinalizeParams F = make_finalize(h, partials, nranks, 1);  // plant on: the state advances on the device
+    if (h->f64) launch_finalize<double>(F, true, (hipStream_t)stream);
+    else launch_finalize<float>(F, true, (hipStream_t)stream);
+    HIPCHECK(h, hipGetLastError());
+    h->begun = false;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, mppi_stats *stats, void *stream) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(h, hipStreamSynchronize(s));
     h->idx = h->h_res->idx_after;
     fill_stats(h, stats);
     if (h->h_res->status == STATUS_PATH_END)

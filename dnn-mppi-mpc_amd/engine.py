@@ -129,9 +129,21 @@ class Engine:
         return n.value
 
     def step_begin(self, x0, eps, partial, stream=None):
-        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        """x0 None: continue from the state on the device (closed loop)."""
+        xp = None
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            xp = _dp(x0)
         self._check_eps(eps)
-        self._ck(self.lib.mppi_step_begin(self._h, _dp(x0), _dev_ptr(eps), _dev_ptr(partial), _stream_ptr(stream)))
+        self._ck(self.lib.mppi_step_begin(self._h, xp, _dev_ptr(eps), _dev_ptr(partial), _stream_ptr(stream)))
+
+    def step_end_async(self, partials, nranks, stream=None):
+        self._ck(self.lib.mppi_step_end_async(self._h, _dev_ptr(partials), int(nranks), _stream_ptr(stream)))
+
+    def sync_result(self, stream=None):
+        u, u0 = np.empty((self.T, 2)), np.empty(2)
+        self._ck(self.lib.mppi_sync_result(self._h, _dp(u), _dp(u0), C.byref(self.stats), _stream_ptr(stream)))
+        return u, u0, self.stats
 
     def step_end(self, partials, nranks, stream=None):
         u, u0 = np.empty((self.T, 2)), np.empty(2)

@@ -156,14 +156,19 @@ int mppi_step(mppi_handle *h, const double *x0, const float *eps, double *u_out,
 /*
  * Split form for K sharded over ranks.  `begin` runs sample ->
  * rollout -> cost -> local softmin partial and writes this rank's record
- * {rho_g, eta_g, W_g[T,2]} (2 + 2T doubles) to `partial` (device).  The caller all-gathers
- * the records over its communicator (RCCL); `end` merges `nranks` records (device,
- * double[nranks, 2+2T]) and finishes the iteration identically on every rank.
+ * {rho_g, eta_g, eta2_g, W_g[T,2]} (3 + 2T doubles, mppi_partial_len) to `partial` (device).
+ * The caller all-gathers the records over its communicator (RCCL); `end` merges `nranks`
+ * records (device, double[nranks, 3+2T]) and finishes the iteration identically on every
+ * rank.  x0 == NULL in `begin` takes the state already on the device (closed loop);
+ * `end_async` then advances it with the plant and returns without synchronising, and
+ * `mppi_sync_result` fetches the outputs of the last finished iteration.
  */
 int mppi_partial_len(const mppi_handle *h, int32_t *n_doubles);
 int mppi_step_begin(mppi_handle *h, const double *x0, const float *eps, double *partial, void *stream);
 int mppi_step_end(mppi_handle *h, const double *partials, int32_t nranks, double *u_out, double *u0_out,
                   mppi_stats *stats, void *stream);
+int mppi_step_end_async(mppi_handle *h, const double *partials, int32_t nranks, void *stream);
+int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, mppi_stats *stats, void *stream);
 
 /* S[K] of the last iteration (`S`, :103) and its weights (`_compute_weight`, :167-180); host doubles */
 int mppi_get_costs(mppi_handle *h, double *S);

@@ -460,3 +460,30 @@ def generate_lemniscate_racecar(num_points, radius):
     yaw = np.arctan2(np.gradient(y), np.gradient(x))
     v = np.ones_like(t) * 5.0
     return np.stack([x, y, yaw, v], axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# K-sharding: per-shard softmin record and its merge, f64
+# --------------------------------------------------------------------------------------
+
+
+def softmin_partial(S, eps, beta):
+    """Record {rho, eta, eta2, W[T,2]} of one shard: W = sum_k exp(-beta (S_k - rho)) eps_k."""
+    S = np.asarray(S, np.float64)
+    eps = np.asarray(eps, np.float64)
+    rho = S.min()
+    e = np.exp(-beta * (S - rho))
+    W = (e[:, None, None] * eps).sum(axis=0)
+    return np.concatenate([[rho, e.sum(), (e * e).sum()], W.reshape(-1)])
+
+
+def merge_partials(records, beta):
+    """Merge shard records with the rescale trick; returns (rho, eta, ess, w_eps[T,2]) equal to the
+    unsharded `_compute_weight` + weighted sum (mppi_race_car.py:199-209, :93-95)."""
+    r = np.asarray(records, np.float64)
+    rho = r[:, 0].min()
+    s = np.exp(-beta * (r[:, 0] - rho))
+    eta = (s * r[:, 1]).sum()
+    eta2 = (s * s * r[:, 2]).sum()
+    W = (s[:, None] * r[:, 3:]).sum(axis=0)
+    return rho, eta, eta * eta / eta2, (W / eta).reshape(-1, 2)
