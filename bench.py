@@ -84,8 +84,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("MPPI_BENCH_FORCE_SHARDED"))  # rehearsal of the N>1 path on 1 GPU
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
 
@@ -97,12 +99,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     def run(n):
-        if world == 1:
+        if not sharded:
             eng.run_closed_loop(n, stream=stream)  # n complete iterations, one sync at the end
         else:
             ctrl.run_closed_loop_sharded(n)
@@ -114,22 +116,39 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     idx_timed = int(eng.stats.idx_after)
 
-    # second pass of the same number of steps with HIP events around every launch (same stream)
+    # Kernel duration, measured live with HIP events on the launch stream over the same number of steps:
+    # (a) the dominant kernel's launch-to-launch duration = growth of the iteration period when that
+    #     (idempotent) kernel is launched twice per iteration -- two events around the whole region, so no
+    #     per-launch event overhead enters; (b) per-launch event pairs with an empty-pair calibration.
+    def timed_region(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record(stream)
+        run(n)
+        e1.record(stream)
+        barrier()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    period_1x = timed_region(args.steps)
+    eng.set_rollout_repeats(2)
+    period_2x = timed_region(args.steps)
+    eng.set_rollout_repeats(1)
+    t_rollout = max(period_2x - period_1x, 1e-9)
     eng.enable_timing(True)
-    run(args.steps)
+    run(min(args.steps, 2000))
     barrier()
     kms = eng.last_kernel_ms()
     eng.enable_timing(False)
 
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
-    if world == 1:
+    if not sharded:
         from oracle import mppi_oracle
         import contextlib
         import io
@@ -145,18 +164,28 @@ def main():
 
     if rank == 0:
         units = K_SAMPLES * world * HORIZON
-        # algorithmic HBM bytes: 16 B per trajectory-step (two passes over the f32
-        # noise) + 8 B per trajectory (S out, S in).  The rollout launch owns one pass: 8 B/step + 4 B/traj.
-        alg_rollout = 8.0 * K_SAMPLES * HORIZON + 4.0 * K_SAMPLES
-        alg_iter = 16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES
-        t_roll = kms["rollout"] * 1e-3
-        t_all = (kms["rollout"] + kms["reduce"] + kms["finalize"]) * 1e-3
-        roof = {"bound": "hbm", "kernel": "k_rollout<float, diffdrive>",
-                "achieved": alg_rollout / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_rollout / t_roll / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel_us": {k: 1e3 * v for k, v in kms.items() if k != "step"},
-                "iteration_achieved_GBs": alg_iter / t_all / 1e9,
-                "note": "noise is drawn in-kernel (Philox), so measured HBM traffic is far below the algorithmic bytes"}
+        # ALGORITHMIC HBM bytes: 16 B per trajectory-step (two passes over the f32
+        # noise: rollout, weighted reduce) + 8 B per trajectory (S out, S in).  k_rollout_fused does BOTH
+        # passes in one launch (the noise stays in registers), so one launch owns the whole figure.
+        alg_bytes = 16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES
+        t_roll = t_rollout
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_file):  # rocprofv3 --pmc passes of this same command (see profiles/README.md)
+            traffic = json.load(open(pmc_file)).get("k_rollout_fused_hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": "k_rollout_fused<float, diffdrive, 1>",
+                "achieved": alg_bytes / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / t_roll / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_us": 1e6 * t_rollout,
+                "period_us": {"1x_rollout": 1e6 * period_1x, "2x_rollout": 1e6 * period_2x},
+                "event_pair_us": {k: 1e3 * v for k, v in kms.items()},
+                "iteration_achieved_GBs": alg_bytes / period_1x / 1e9,
+                "note": "kernel_us = launch-to-launch duration of k_rollout_fused on its stream (period with the kernel "
+                        "launched twice per iteration minus the normal period, HIP events around the whole region); "
+                        "event_pair_us = per-launch event pairs minus the empty-pair calibration (excludes dispatch). "
+                        "Noise is drawn in-kernel (Philox) and never touches HBM, so PMC traffic is far below the "
+                        "algorithmic bytes: the launch is VALU-issue/latency bound, not HBM bound"}
         out = {"metric": "trajectory-steps/sec (KxT/iter_time), diff-drive K=4096 T=50", "value": units * args.steps / dt,
                "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -164,7 +193,7 @@ def main():
                "config": {"workload": "BASELINE config 2: differential-drive analytic dynamics, K=4096 x T=50 per GPU, "
                                       "reference __main__ parameters, closed loop with the driver's plant on the device",
                           "K_per_gpu": K_SAMPLES, "K_global": K_SAMPLES * world, "T": HORIZON,
-                          "waypoint_mode": "sequential (reference-exact)" if world == 1 else "frozen (K-sharded)",
+                          "waypoint_mode": "frozen (K-sharded)" if sharded else "sequential (reference-exact)",
                           "noise": "Philox4x32-10 in-kernel", "waypoint_idx_during_timing": idx_timed},
                "iter_latency_us": 1e6 * dt / args.steps,
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
@@ -172,7 +201,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mppi_run_closed_loop": (C.c_int, [_H, C.c_int32, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_last_kernel_ms": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "mppi_enable_timing": (C.c_int, [_H, C.c_int32]),
+    "mppi_set_rollout_repeats": (C.c_int, [_H, C.c_int32]),
 }
 
 _lib = None

@@ -52,6 +52,7 @@ class _ControllerBase:
         cfg.update(precision=capi.PREC_F64 if precision in ("f64", "float64") else capi.PREC_F32,
                    device=int(device), seed=int(seed), collision_penalty=1.0e10, filter_window=10)
         self._pg = process_group
+        self._sharded = process_group is not None  # split step + all-gather, even on a 1-rank group
         self._world, self._rank = 1, 0
         if process_group is not None:
             import torch.distributed as dist
@@ -152,7 +153,7 @@ class _ControllerBase:
         x0 = _arr(observed_x).reshape(-1)
         self._sync_state_to_device()
         eps = self._device_eps()
-        if self._world == 1:
+        if not self._sharded:
             u, u0, st = self._engine.step(x0, eps)
         else:
             u, u0, st = self._sharded_step(x0, eps)

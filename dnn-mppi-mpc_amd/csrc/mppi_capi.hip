@@ -32,9 +32,9 @@ struct mppi_handle {
     StepResult *d_res = nullptr, *h_res = nullptr;
     size_t res_bytes = 0;
     const float *last_eps = nullptr;
-    bool last_philox = true, begun = false, timing = false, dev_loop_primed = false;
+    bool last_philox = true, begun = false, timing = false, dev_loop_primed = false, slot_timed = false;
     long long iter = 0;
-    int idx = 0;
+    int idx = 0, rollout_repeats = 1;
     std::vector<hipEvent_t> ev;  // pairs around the rollout / reduce / finalize kernels
     size_t ev_used = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr};
@@ -416,6 +416,13 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     return F;
 }
 
+// Timing (mppi_enable_timing): every launch group of a slot is bracketed by a pair of events on the
+// launch stream -- [rollout] [reduce/merge] [finalize] -- plus one EMPTY pair that measures what a pair
+// of hipEventRecord costs on this stream (several microseconds); mppi_last_kernel_ms reports the
+// averages with that calibration subtracted.
+constexpr int EV_PER_SLOT = 8;
+constexpr size_t EV_MAX = 8u * 200000u;
+
 static hipEvent_t next_event(mppi_handle *h) {
     if (h->ev_used == h->ev.size()) {
         hipEvent_t e;
@@ -425,17 +432,20 @@ static hipEvent_t next_event(mppi_handle *h) {
     return h->ev[h->ev_used++];
 }
 
+static bool timing_on(const mppi_handle *h) { return h->timing && h->ev_used + EV_PER_SLOT <= EV_MAX; }
+
 // Softmin partial records of this handle's samples: rollout (+ reduce when not fused), and for large K a
 // 64:1 merge so that the finalize block never reads more than MAX_FINAL_PARTS records.
 constexpr int MAX_FINAL_PARTS = 256;  // = MERGE_MAX_RECORDS of the kernels
 
 template <typename R>
 static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const void **recs,
-                         int *n_recs) {
-    const bool tm = h->timing;
+                         int *n_recs, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
-    if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
-    else launch_rollout<R>(P, s);
+    for (int rep = 0; rep < h->rollout_repeats; ++rep) {
+        if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
+        else launch_rollout<R>(P, s);
+    }
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
     if (!h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
@@ -450,30 +460,38 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     if (tm) hipEventRecord(next_event(h), s);
 }
 
-// rollout (-> reduce) -> finalize, each optionally bracketed by events (6 events per slot)
 template <typename R>
-static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
-    const bool tm = h->timing;
-    launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part);
+static void launch_back(mppi_handle *h, const FinalizeParams &F, bool abi_recs, hipStream_t s, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
-    launch_finalize<R>(F, false, s);
+    launch_finalize<R>(F, abi_recs, s);
+    if (tm) hipEventRecord(next_event(h), s);
+    if (tm) hipEventRecord(next_event(h), s);  // empty pair: the cost of the bracketing itself
     if (tm) hipEventRecord(next_event(h), s);
 }
 
+// rollout (-> reduce) -> finalize
+template <typename R>
+static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
+    const bool tm = timing_on(h);
+    launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part, tm);
+    launch_back<R>(h, F, false, s, tm);
+}
+
 static void collect_timing(mppi_handle *h) {
-    if (!h->timing) return;
-    double acc[3] = {0, 0, 0};
-    const size_t slots = h->ev_used / 6;
+    double acc[4] = {0, 0, 0, 0};
+    const size_t slots = h->ev_used / EV_PER_SLOT;
     for (size_t i = 0; i < slots; ++i)
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 4; ++j) {
             float ms = 0;
-            hipEventElapsedTime(&ms, h->ev[6 * i + 2 * j], h->ev[6 * i + 2 * j + 1]);
+            hipEventElapsedTime(&ms, h->ev[EV_PER_SLOT * i + 2 * j], h->ev[EV_PER_SLOT * i + 2 * j + 1]);
             acc[j] += ms;
         }
-    for (int j = 0; j < 3; ++j) h->last_ms[j] = slots ? (float)(acc[j] / slots) : 0.f;
-    float ms = 0;
-    hipEventElapsedTime(&ms, h->ev_step[0], h->ev_step[1]);
-    h->last_ms[3] = ms;
+    const double cal = slots ? acc[3] / slots : 0.0;
+    for (int j = 0; j < 3; ++j) {
+        const double v = slots ? acc[j] / slots - cal : 0.0;
+        h->last_ms[j] = (float)(v > 0 ? v : 0);
+    }
+    h->last_ms[3] = (float)cal;
 }
 
 static int check_ready(mppi_handle *h, const char *who) {
@@ -502,19 +520,15 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
                      mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    h->ev_used = 0;
-    if (h->timing) hipEventRecord(h->ev_step[0], s);
     launch_set_state<R>(P, x0, s);
     for (int round = 0;; ++round) {
         launch_slot<R>(h, P, F, s);
         HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
-        if (h->timing) hipEventRecord(h->ev_step[1], s);
         HIPCHECK(h, hipStreamSynchronize(s));
         HIPCHECK(h, hipGetLastError());
         if (h->h_res->status != STATUS_NEED_ROUND) break;
         if (round > h->cfg.K + 1) FAIL(h, MPPI_ERR_STATE, "waypoint speculation did not converge");
     }
-    collect_timing(h);
     h->dev_loop_primed = false;
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
@@ -556,7 +570,8 @@ static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double
     // closed loop on the device: the previous end_async already made the x0 call for the new state
     if (x0 || !h->dev_loop_primed) launch_set_state<R>(P, x0, s);
     h->dev_loop_primed = x0 == nullptr;
-    launch_front<R>(h, P, F.beta, s, &recs, &n_recs);
+    h->slot_timed = timing_on(h);
+    launch_front<R>(h, P, F.beta, s, &recs, &n_recs, h->slot_timed);
     launch_merge<R>(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, true, s);  // this rank's single record (f64)
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;
@@ -589,8 +604,8 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     FinalizeParams F = make_finalize(h, partials, nranks, 0);
-    if (h->f64) launch_finalize<double>(F, true, s);
-    else launch_finalize<float>(F, true, s);
+    if (h->f64) launch_back<double>(h, F, true, s, h->slot_timed);
+    else launch_back<float>(h, F, true, s, h->slot_timed);
     HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
     HIPCHECK(h, hipStreamSynchronize(s));
     HIPCHECK(h, hipGetLastError());
@@ -615,8 +630,8 @@ extern "C" int mppi_step_end_async(mppi_handle *h, const double *partials, int32
     if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end_async without mppi_step_begin");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     FinalizeParams F = make_finalize(h, partials, nranks, 1);  // plant on: the state advances on the device
-    if (h->f64) launch_finalize<double>(F, true, (hipStream_t)stream);
-    else launch_finalize<float>(F, true, (hipStream_t)stream);
+    if (h->f64) launch_back<double>(h, F, true, (hipStream_t)stream, h->slot_timed);
+    else launch_back<float>(h, F, true, (hipStream_t)stream, h->slot_timed);
     HIPCHECK(h, hipGetLastError());
     h->begun = false;
     return MPPI_OK;
@@ -706,8 +721,6 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         F.u0_trace = h->d_trace - 2 * h->iter;  // the kernel indexes by the absolute iteration
     }
     const long long target = h->iter + n_iters;
-    h->ev_used = 0;
-    if (h->timing) hipEventRecord(h->ev_step[0], s);
     launch_set_state<R>(P, nullptr, s);  // x0 call for the state already on the device
     long long done = h->iter;
     int guard = 0;
@@ -715,14 +728,12 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         const long long todo = target - done;
         for (long long i = 0; i < todo; ++i) launch_slot<R>(h, P, F, s);
         HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
-        if (h->timing) hipEventRecord(h->ev_step[1], s);
         HIPCHECK(h, hipStreamSynchronize(s));
         HIPCHECK(h, hipGetLastError());
         if (h->h_res->status == STATUS_PATH_END) break;
         done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
         if (++guard > h->cfg.K + 8) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
     }
-    collect_timing(h);
     h->last_eps = nullptr;
     h->last_philox = true;
     h->idx = h->h_res->idx_after;
@@ -747,12 +758,22 @@ extern "C" int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_
 
 extern "C" int mppi_enable_timing(mppi_handle *h, int32_t on) {
     if (!h) return MPPI_ERR_BAD_ARG;
+    if (on && !h->timing) h->ev_used = 0;  // a new measurement window
     h->timing = on != 0;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_set_rollout_repeats(mppi_handle *h, int32_t n) {
+    if (!h || n < 1 || n > 64) return MPPI_ERR_BAD_ARG;
+    h->rollout_repeats = n;
     return MPPI_OK;
 }
 
 extern "C" int mppi_last_kernel_ms(mppi_handle *h, float *out4) {
     if (!h || !out4) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());  // every recorded event has completed
+    collect_timing(h);
     memcpy(out4, h->last_ms, sizeof(h->last_ms));
     return MPPI_OK;
 }

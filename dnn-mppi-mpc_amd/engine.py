@@ -185,7 +185,10 @@ class Engine:
     def enable_timing(self, on=True):
         self._ck(self.lib.mppi_enable_timing(self._h, int(bool(on))))
 
+    def set_rollout_repeats(self, n):
+        self._ck(self.lib.mppi_set_rollout_repeats(self._h, int(n)))
+
     def last_kernel_ms(self):
         out = (C.c_float * 4)()
         self._ck(self.lib.mppi_last_kernel_ms(self._h, out))
-        return {"rollout": out[0], "reduce": out[1], "finalize": out[2], "step": out[3]}
+        return {"rollout": out[0], "reduce": out[1], "finalize": out[2], "event_pair_overhead": out[3]}

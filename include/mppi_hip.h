@@ -197,10 +197,17 @@ int mppi_get_state(mppi_handle *h, double *x);
 int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_trace /* host, nullable [n_iters,2] */,
                          mppi_stats *stats, void *stream);
 
-/* duration (ms, HIP events on `stream`) of the last step's kernels:
- * out[0] rollout+cost, out[1] softmin reduce, out[2] finalise, out[3] whole step */
+/* Kernel durations by HIP events on the launch stream.  While enabled, every launch group of every
+ * iteration is bracketed by an event pair, plus one empty pair that calibrates the cost of the
+ * bracketing itself.  mppi_last_kernel_ms: averages (ms) over the window since timing was enabled,
+ * calibration subtracted: out[0] rollout+cost(+fused softmin partial), out[1] separate reduce / merge
+ * launches (0 when fused), out[2] finalise, out[3] the empty-pair calibration itself. */
 int mppi_last_kernel_ms(mppi_handle *h, float *out4);
 int mppi_enable_timing(mppi_handle *h, int32_t on);
+/* Measurement aid: launch the rollout kernel `n` >= 1 times per iteration (it is idempotent -- same
+ * state in, same S / partial records out).  The growth of the iteration period per extra launch is that
+ * kernel's launch-to-launch duration on the stream, free of any event overhead (bench.py). */
+int mppi_set_rollout_repeats(mppi_handle *h, int32_t n);
 
 #ifdef __cplusplus
 }
