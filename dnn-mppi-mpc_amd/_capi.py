@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmppi_hip.so")
 
 # enums of mppi_hip.h
-MODEL_DIFFDRIVE, MODEL_RACECAR = 0, 1
+MODEL_DIFFDRIVE, MODEL_RACECAR, MODEL_DIFFDRIVE_MLP = 0, 1, 2
 PREC_F32, PREC_F64 = 0, 1
 WAYPOINT_SEQUENTIAL, WAYPOINT_FROZEN = 0, 1
 BETA_INV_EXPLORATION, BETA_INV_LAMBDA, BETA_LAMBDA = 0, 1, 2
@@ -60,6 +60,9 @@ PROTOTYPES = {
     "mppi_destroy": (C.c_int, [_H]),
     "mppi_set_ref_path": (C.c_int, [_H, _D, C.c_int32, C.c_int32]),
     "mppi_set_obstacles": (C.c_int, [_H, _D, C.c_int32]),
+    "mppi_set_mlp": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                              C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                              C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mppi_set_u_prev": (C.c_int, [_H, _D]),
     "mppi_get_u_prev": (C.c_int, [_H, _D]),
     "mppi_set_waypoint_idx": (C.c_int, [_H, C.c_int32]),

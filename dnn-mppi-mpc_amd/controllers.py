@@ -240,7 +240,7 @@ class MPPIAlgorithms(_ControllerBase):
                  param_lambda, param_alpha, sigma, stage_cost_weight, terminal_cost_weight, obstacle_circles=None,
                  safety_margin_rate=None, visualize_optimal_traj=True, visualze_sampled_trajs=True,
                  visualize_sampled_traj=None, *, variant="numpy", precision="f32", device=0, seed=0,
-                 process_group=None, waypoint_mode=None):
+                 process_group=None, waypoint_mode=None, learned_dynamics=None):
         if visualize_sampled_traj is not None:  # the torch variant's spelling (:63-64)
             visualze_sampled_trajs = visualize_sampled_traj
         self.delta_t = _num(delta_t)
@@ -265,8 +265,13 @@ class MPPIAlgorithms(_ControllerBase):
             raise ValueError(f"could not broadcast input array from shape (10,) into shape ({self.T},)")
         if waypoint_mode is None:
             waypoint_mode = "sequential" if process_group is None else "frozen"
+        if learned_dynamics is not None and hasattr(learned_dynamics, "state_dict"):
+            learned_dynamics = learned_dynamics.state_dict()  # a torch module (train/train_diff_mlp.py:13-36)
+        if learned_dynamics is not None:  # BASELINE config 5: no visualisation rollouts for this model
+            self.visualze_sampled_trajs_requested = self.visualze_sampled_trajs
         cfg = dict(
-            model=capi.MODEL_DIFFDRIVE, K=self.K, T=self.T, delta_t=self.delta_t,
+            model=capi.MODEL_DIFFDRIVE if learned_dynamics is None else capi.MODEL_DIFFDRIVE_MLP,
+            K=self.K, T=self.T, delta_t=self.delta_t,
             u_max=[self.max_speed, self.max_omega], wheel_base=0.0,
             param_exploration=self.param_exploration, param_lambda=self.param_lambda, param_alpha=self.param_alpha,
             sigma=self.Sigma, stage_cost_weight=self.stage_cost_weight, terminal_cost_weight=self.terminal_cost_weight,
@@ -284,6 +289,9 @@ class MPPIAlgorithms(_ControllerBase):
             vehicle_w=0.0, vehicle_l=0.0,
         )
         self._finish_init(cfg, ref_path, obstacle_circles, precision, device, seed, process_group)
+        self._learned = learned_dynamics is not None
+        if self._learned:
+            self._engine.set_mlp(learned_dynamics)
 
     prev_way_point_idx = property(_ControllerBase._get_idx, _ControllerBase._set_idx)
 
@@ -294,7 +302,8 @@ class MPPIAlgorithms(_ControllerBase):
         if st.path_end:
             print("[ERROR] Reached the end of the reference path.")  # :98
         # both viz rollouts hang off `visualze_sampled_trajs` in the reference (:145,:154)
-        opt, smp = self._viz(self.visualze_sampled_trajs, self.visualze_sampled_trajs)
+        want = self.visualze_sampled_trajs and not self._learned
+        opt, smp = self._viz(want, want)
         return self._u_host[0], self._u_host, opt, smp
 
     def _g(self, v):

@@ -23,6 +23,9 @@ struct mppi_handle {
     bool fused = false;       // rollout + softmin partial in one launch (T <= 128)
     int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
+    float *d_mlp = nullptr;         // packed residual-model weights (config 5)
+    MlpParams mlp;
+    bool mlp_set = false;
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
     int *d_pout = nullptr;
     void *d_partials = nullptr;     // block records in the handle's precision
@@ -103,8 +106,10 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (c.K < 1 || c.T < 1 || c.K_global < c.K || c.k_offset < 0 || c.k_offset + c.K > c.K_global)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: bad K=%d T=%d K_global=%d k_offset=%d", c.K, c.T,
              c.K_global, c.k_offset);
-    if (c.model != MPPI_MODEL_DIFFDRIVE && c.model != MPPI_MODEL_RACECAR)
+    if (c.model != MPPI_MODEL_DIFFDRIVE && c.model != MPPI_MODEL_RACECAR && c.model != MPPI_MODEL_DIFFDRIVE_MLP)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown model %d", c.model);
+    if (c.model == MPPI_MODEL_DIFFDRIVE_MLP && c.precision != MPPI_PREC_F32)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED, "the learned-dynamics rollout runs on the f32 MFMA path only");
     if (c.precision != MPPI_PREC_F32 && c.precision != MPPI_PREC_F64)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown precision %d", c.precision);
     if (c.filter_window < 1) c.filter_window = 10;
@@ -154,6 +159,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
     h->n_part = h->fused ? fused_blocks(c.K) : h->n_blocks;
+    if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
     auto fail = [&](hipError_t e, const char *what) {
         g_create_error = std::string(what) + " failed: " + hipGetErrorString(e);
@@ -196,7 +202,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
 extern "C" int mppi_destroy(mppi_handle *h) {
     if (!h) return MPPI_OK;
     hipSetDevice(h->cfg.device);
-    void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2,
+    void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
                     h->d_w,   h->d_trace, h->d_st, h->d_res};
     for (void *b : bufs)
         if (b) hipFree(b);
@@ -245,6 +251,39 @@ extern "C" int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m) 
     }
     HIPCHECK(h, hipMalloc(&h->d_obs, rsz(h) * 4 * m));
     return upload_real(h, h->d_obs, packed.data(), packed.size());
+}
+
+extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
+                            const float *const *w_hidden, const float *const *b_hidden, const float *w_out,
+                            const float *b_out) {
+    if (!h || !w_in || !b_in || !w_hidden || !b_hidden || !w_out || !b_out)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp: null argument");
+    if (h->cfg.model != MPPI_MODEL_DIFFDRIVE_MLP) FAIL(h, MPPI_ERR_STATE, "mppi_set_mlp needs MPPI_MODEL_DIFFDRIVE_MLP");
+    if (hidden != 512 || n_hidden != 3)
+        FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: only Linear(5,512) -> 3 x Linear(512,512) -> Linear(512,3) is built");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    const size_t n_in = 16 * 1 * 64 * 4, n_h = 16 * 64 * 64 * 4, total = n_in + 512 + 3 * (n_h + 512) + 3 * 512;
+    std::vector<float> host(total);
+    size_t o = 0;
+    const size_t o_win = o; pack_linear(w_in, 5, host.data() + o); o += n_in;
+    const size_t o_bin = o; memcpy(host.data() + o, b_in, 512 * sizeof(float)); o += 512;
+    size_t o_wh[3], o_bh[3];
+    for (int l = 0; l < 3; ++l) {
+        if (!w_hidden[l] || !b_hidden[l]) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp: null hidden layer %d", l);
+        o_wh[l] = o; pack_linear(w_hidden[l], 512, host.data() + o); o += n_h;
+        o_bh[l] = o; memcpy(host.data() + o, b_hidden[l], 512 * sizeof(float)); o += 512;
+    }
+    const size_t o_wo = o; memcpy(host.data() + o, w_out, 3 * 512 * sizeof(float)); o += 3 * 512;
+    if (!h->d_mlp) HIPCHECK(h, hipMalloc((void **)&h->d_mlp, total * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(h->d_mlp, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    h->mlp.w_in = h->d_mlp + o_win;
+    h->mlp.b_in = h->d_mlp + o_bin;
+    for (int l = 0; l < 3; ++l) { h->mlp.w_h[l] = h->d_mlp + o_wh[l]; h->mlp.b_h[l] = h->d_mlp + o_bh[l]; }
+    h->mlp.w_out = h->d_mlp + o_wo;
+    for (int i = 0; i < 3; ++i) h->mlp.b_out[i] = b_out[i];
+    h->mlp_set = true;
+    return MPPI_OK;
 }
 
 extern "C" int mppi_set_u_prev(mppi_handle *h, const double *u) {
@@ -329,7 +368,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.n_ref = h->n_ref;
     P.n_obs = c.obstacle_model == MPPI_OBSTACLE_NONE ? 0 : h->n_obs;
     P.window = c.search_window;
-    P.model = c.model;
+    P.model = c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF;
     P.accumulate = c.accumulate_stage_cost;
     P.sequential = c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL;
     P.obstacle_model = P.n_obs > 0 ? c.obstacle_model : OBS_NONE;
@@ -391,7 +430,7 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.filter_window = c.filter_window;
     F.clamp_u = c.clamp_u_after_update;
     F.raise_at_path_end = c.raise_at_path_end;
-    F.model = c.model;
+    F.model = c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF;
     F.sequential = c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL;
     F.plant = plant;
     F.n_ref = h->n_ref;
@@ -438,17 +477,24 @@ static bool timing_on(const mppi_handle *h) { return h->timing && h->ev_used + E
 // 64:1 merge so that the finalize block never reads more than MAX_FINAL_PARTS records.
 constexpr int MAX_FINAL_PARTS = 256;  // = MERGE_MAX_RECORDS of the kernels
 
+static void launch_mlp(mppi_handle *h, const KParams<float> &P, hipStream_t s) {
+    launch_rollout_mlp(P, h->mlp, h->d_partials, s);
+}
+static void launch_mlp(mppi_handle *, const KParams<double> &, hipStream_t) {}  // rejected at create
+
 template <typename R>
 static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const void **recs,
                          int *n_recs, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
+    const bool mlp = h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP;
     for (int rep = 0; rep < h->rollout_repeats; ++rep) {
-        if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
+        if (mlp) launch_mlp(h, P, s);
+        else if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
         else launch_rollout<R>(P, s);
     }
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
-    if (!h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    if (!mlp && !h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
     *recs = h->d_partials;
     *n_recs = h->n_part;
     if (h->n_part > MAX_FINAL_PARTS) {
@@ -499,6 +545,8 @@ static int check_ready(mppi_handle *h, const char *who) {
     if (!h->d_ref || h->n_ref < 1) FAIL(h, MPPI_ERR_STATE, "%s: ref_path has not been set", who);
     if (h->cfg.obstacle_model != MPPI_OBSTACLE_NONE && h->n_obs > 0 && !h->d_obs)
         FAIL(h, MPPI_ERR_STATE, "%s: obstacles not uploaded", who);
+    if (h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP && !h->mlp_set)
+        FAIL(h, MPPI_ERR_STATE, "%s: mppi_set_mlp has not been called", who);
     return MPPI_OK;
 }
 
@@ -691,6 +739,8 @@ extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *samp
     int rc = check_ready(h, "mppi_rollout_viz");
     if (rc) return rc;
     if (h->iter < 1) FAIL(h, MPPI_ERR_STATE, "mppi_rollout_viz before the first mppi_step");
+    if (h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "visualisation rollouts are not built for the learned-dynamics model");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     const float *eps = h->last_philox ? nullptr : h->last_eps;
     const int T = h->cfg.T;

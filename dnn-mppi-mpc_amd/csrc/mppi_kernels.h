@@ -79,6 +79,14 @@ struct FinalizeParams {
     double *u0_trace;        // nullable: closed-loop trace [iter][2]
 };
 
+// learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights
+struct MlpParams {
+    const float *w_in, *b_in;        // Linear(5 -> 512): packed [16][1][64][4], bias [512]
+    const float *w_h[3], *b_h[3];    // Linear(512 -> 512) x 3: packed [16][64][64][4], bias [512]
+    const float *w_out;              // Linear(512 -> 3): [3][512] as in the checkpoint
+    float b_out[3];
+};
+
 struct VizParams {
     int K, T, model, clamp_rollout;
     int k_offset, n_exploit, use_philox, pad;
@@ -107,5 +115,10 @@ template <typename R>
 void launch_viz(const KParams<R> &P, const R *u_before, const R *u_after_pre_shift, long long iter, float *opt,
                 float *smp, hipStream_t s);
 int reduce_blocks(int K, int traj_per_block);
+// config 5: rollout through the residual MLP on MFMA, one record per 64-sample tile
+void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s);
+int mlp_blocks(int K);
+void pack_linear(const float *w, int n_in, float *packed);  // host: [512][n_in] -> fragment order
+constexpr int MODEL_DIFF_MLP = 2;
 
 }  // namespace mppi

@@ -73,6 +73,27 @@ class Engine:
         c = np.ascontiguousarray(circles, dtype=np.float64).reshape(-1, 3)
         self._ck(self.lib.mppi_set_obstacles(self._h, _dp(c), c.shape[0]))
 
+    def set_mlp(self, weights):
+        """Residual-model weights in the checkpoint's key layout (``state_dict`` of the reference's
+        ``MultiLayerPerceptron``, train/train_diff_mlp.py:13-36); tensors or arrays."""
+        def arr(k):
+            v = weights[k]
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            return np.ascontiguousarray(v, dtype=np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        n_hidden = sum(1 for k in weights if k.startswith("hidden_layer.") and k.endswith(".weight"))
+        w_in, b_in = arr("input_layer.weight"), arr("input_layer.bias")
+        wh = [arr(f"hidden_layer.{i}.weight") for i in range(n_hidden)]
+        bh = [arr(f"hidden_layer.{i}.bias") for i in range(n_hidden)]
+        w_out, b_out = arr("out_layer.weight"), arr("out_layer.bias")
+        hidden = w_in.shape[0]
+        if w_in.shape != (hidden, 5) or w_out.shape != (3, hidden) or any(w.shape != (hidden, hidden) for w in wh):
+            raise ValueError("unexpected MLP shapes (expected Linear(5,H) -> n x Linear(H,H) -> Linear(H,3))")
+        PP = C.POINTER(C.c_float) * max(1, n_hidden)
+        self._ck(self.lib.mppi_set_mlp(self._h, hidden, n_hidden, fp(w_in), fp(b_in), PP(*[fp(w) for w in wh]),
+                                       PP(*[fp(b) for b in bh]), fp(w_out), fp(b_out)))
+
     def set_u_prev(self, u):
         u = np.ascontiguousarray(u, dtype=np.float64)
         if u.shape != (self.T, 2):

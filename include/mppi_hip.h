@@ -39,7 +39,13 @@ typedef enum {
 } mppi_status;
 
 /* dynamics: controllers/mppi_differential_drive.py:182-198 / controllers/mppi_race_car.py:183-197 */
-typedef enum { MPPI_MODEL_DIFFDRIVE = 0, MPPI_MODEL_RACECAR = 1 } mppi_model;
+typedef enum {
+    MPPI_MODEL_DIFFDRIVE = 0,
+    MPPI_MODEL_RACECAR = 1,
+    /* unicycle + learned residual, x' = x + dt (f(x,v) + MLP([x,v])) (test/bullet_differential_drive_dnn.py:79-92);
+     * needs mppi_set_mlp; fp32 only (f32 MFMA) */
+    MPPI_MODEL_DIFFDRIVE_MLP = 2
+} mppi_model;
 /* arithmetic type of the rollout/cost kernels (the noise tensor is always f32) */
 typedef enum { MPPI_PREC_F32 = 0, MPPI_PREC_F64 = 1 } mppi_precision;
 /* waypoint search state, SURVEY.md App. A.3:
@@ -132,6 +138,14 @@ int mppi_destroy(mppi_handle *h);
 int mppi_set_ref_path(mppi_handle *h, const double *path, int32_t n, int32_t ncols);
 /* `self.obstacle_circles` (host, [m,3] = x,y,r) */
 int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m);
+/*
+ * Weights of the residual model `MultiLayerPerceptron` (train/train_diff_mlp.py:13-36), host float arrays in the
+ * checkpoint's own layout (saved_models/mlp_diff_300x100_3l.pth): input_layer.weight [512,5], .bias [512];
+ * hidden_layer.{0,1,2}.weight [512,512], .bias [512]; out_layer.weight [3,512], .bias [3].
+ * hidden must be 512 and n_hidden 3 (the architecture the reference trains).
+ */
+int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
+                 const float *const *w_hidden, const float *const *b_hidden, const float *w_out, const float *b_out);
 /* mutable controller state: `u_prev[T,2]` and `prev_way_point_idx` / `prev_waypoints_idx`
  * (mppi_differential_drive.py:82,:85); host pointers */
 int mppi_set_u_prev(mppi_handle *h, const double *u);

@@ -487,3 +487,59 @@ def merge_partials(records, beta):
     eta2 = (s * s * r[:, 2]).sum()
     W = (s[:, None] * r[:, 3:]).sum(axis=0)
     return rho, eta, eta * eta / eta2, (W / eta).reshape(-1, 2)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config 5: the diff-drive MPPI loop with learned residual dynamics (build-defined composition,
+# SURVEY.md section 3.3): x_{t+1} = x_t + dt * (f(x_t, v_t) + MLP([x_t, v_t])), f = [v cos(yaw), v sin(yaw), w]
+# (test/bullet_differential_drive_dnn.py:79-92); MLP = train/train_diff_mlp.py:13-36
+# (Linear(5,512) -> 3 x [Linear(512,512) + tanh] -> Linear(512,3); the first layer has no activation).
+# --------------------------------------------------------------------------------------
+
+
+def mlp_forward(weights, z):
+    """`MultiLayerPerceptron.forward` train/train_diff_mlp.py:31-36 in f64.  weights: dict with the
+    checkpoint's key layout (input_layer.*, hidden_layer.{0,1,2}.*, out_layer.*); z: [..., 5]."""
+    w = {k: np.asarray(v, np.float64) for k, v in weights.items()}
+    h = z @ w["input_layer.weight"].T + w["input_layer.bias"]
+    i = 0
+    while f"hidden_layer.{i}.weight" in w:
+        h = np.tanh(h @ w[f"hidden_layer.{i}.weight"].T + w[f"hidden_layer.{i}.bias"])
+        i += 1
+    return h @ w["out_layer.weight"].T + w["out_layer.bias"]
+
+
+def random_mlp_weights(seed=0, hidden=512, n_hidden=3, out_scale=0.05):
+    """Random weights of the reference architecture, magnitudes like saved_models/mlp_diff_300x100_3l.pth
+    (SURVEY.md App. C); the checkpoint itself cannot travel to the GPU box."""
+    rng = np.random.default_rng(seed)
+    w = {"input_layer.weight": rng.normal(0, 0.2, (hidden, 5)).astype(np.float32),
+         "input_layer.bias": rng.normal(0, 0.15, hidden).astype(np.float32)}
+    for i in range(n_hidden):
+        w[f"hidden_layer.{i}.weight"] = rng.normal(0, 0.045, (hidden, hidden)).astype(np.float32)
+        w[f"hidden_layer.{i}.bias"] = rng.normal(0, 0.02, hidden).astype(np.float32)
+    w["out_layer.weight"] = rng.normal(0, out_scale / np.sqrt(hidden) * 4, (3, hidden)).astype(np.float32)
+    w["out_layer.bias"] = rng.normal(0, 0.01, 3).astype(np.float32)
+    return w
+
+
+class DiffDriveMlpOracle(DiffDriveOracle):
+    """DiffDriveOracle with `_state_transition` replaced by the residual model; cost, waypoint index,
+    weights, filter and shift are the reference's (inherited)."""
+
+    def __init__(self, *a, mlp_weights=None, **kw):
+        super().__init__(*a, **kw)
+        self.mlp_weights = mlp_weights
+
+    def rollout(self, x0, v):
+        K, T = v.shape[:2]
+        dt = self.delta_t
+        X = np.empty((K, T, 3))
+        s = np.tile(np.asarray(x0, np.float64), (K, 1))
+        for t in range(T):
+            z = np.concatenate([s, v[:, t]], axis=1)
+            r = mlp_forward(self.mlp_weights, z)
+            f = np.stack([v[:, t, 0] * np.cos(s[:, 2]), v[:, t, 0] * np.sin(s[:, 2]), v[:, t, 1]], axis=1)
+            s = s + dt * (f + r)
+            X[:, t] = s
+        return X

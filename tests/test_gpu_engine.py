@@ -252,3 +252,69 @@ def test_long_horizons_against_oracle(T):
     np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-8, atol=1e-10)
     assert c.prev_way_point_idx == ref["idx_after"]
+
+
+def _mlp_case(K, T, seed, **over):
+    kw = dd_kwargs(K, T, param_exploration=0.05, **over)
+    w = mppi_oracle.random_mlp_weights(seed)
+    eps = philox.sample_epsilon(kw["sigma"], 31 + seed, 0, K, T)
+    return kw, w, eps
+
+
+@pytest.mark.parametrize("waypoint_mode", ["sequential", "frozen"])
+def test_learned_dynamics_mfma_rollout_against_oracle(waypoint_mode):
+    """Config 5 (scaled down so the f64 NumPy oracle takes seconds): rollout through the residual MLP on the
+    f32 matrix cores vs the f64 restatement.  Tolerance: the north-star 1e-4 RMSE on u; S to 1e-3 relative
+    (f32 MFMA chains through 3 x 512-wide layers and 30 recurrent steps)."""
+    import dnn_mppi_mpc_amd as pkg
+    K, T = 1500, 30
+    kw, w, eps = _mlp_case(K, T, 1)
+    x0 = np.array([0.4, -0.1, -0.35])
+    tt = np.arange(T)
+    u_in = np.stack([1.2 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1)
+    o = mppi_oracle.DiffDriveMlpOracle(**kw, mlp_weights=w)
+    o.u_prev[:] = u_in
+    if waypoint_mode == "frozen":  # frozen index: every call searches from the x0 index (race-car semantics)
+        p0 = o.nearest_waypoint(x0[0], x0[1], 0)
+        v = o.clamp(np.where((np.arange(K) < mppi_oracle.exploit_threshold(kw["param_exploration"], K))[:, None, None],
+                             u_in[None] + eps, eps.astype(np.float64)))
+        X = o.rollout(x0, v)
+        R = o.ref_path
+        win = R[p0:p0 + 20]
+        xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+        i = p0 + np.argmin((xT[:, None] - win[:, 0]) ** 2 + (yT[:, None] - win[:, 1]) ** 2, axis=1)
+        ws, wt = o.stage_cost_weight, o.terminal_cost_weight
+        q = u_in[T - 1] @ np.linalg.inv(o.Sigma)
+        S_ref = ((ws[0] + wt[0]) * (xT - R[i, 0]) ** 2 + (ws[1] + wt[1]) * (yT - R[i, 1]) ** 2
+                 + (ws[2] + wt[2]) * (yawT - R[i, 2]) ** 2 + o.param_gamma * (q[0] * v[:, -1, 0] + q[1] * v[:, -1, 1]))
+        ref = None
+    else:
+        ref = o.iteration(x0, eps.astype(np.float64))
+        S_ref = ref["S"]
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode=waypoint_mode)
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: eps
+    u = c._calc_input_control(x0)[1]
+    S = c.sample_costs()
+    np.testing.assert_allclose(S, S_ref, rtol=1e-3, atol=1e-3)
+    if ref is not None:
+        assert rmse(u, ref["u_returned"]) <= 1e-4
+        assert c.prev_way_point_idx == ref["idx_after"]
+
+
+def test_learned_dynamics_zero_residual_equals_analytic_kernel():
+    """out_layer = 0: the MFMA rollout must reproduce the analytic scan kernel (same costs, same update)."""
+    import dnn_mppi_mpc_amd as pkg
+    kw, w, eps = _mlp_case(1024, 40, 2)
+    w["out_layer.weight"][:] = 0
+    w["out_layer.bias"][:] = 0
+    x0 = np.array([0.2, 0.1, -0.5])
+    a = pkg.MPPIAlgorithms(**kw)
+    b = pkg.MPPIAlgorithms(**kw, learned_dynamics=w)
+    for c in (a, b):
+        c._calc_epsilon = lambda *aa, **k: eps
+    ua = a._calc_input_control(x0)[1].copy()
+    ub = b._calc_input_control(x0)[1].copy()
+    np.testing.assert_allclose(b.sample_costs(), a.sample_costs(), rtol=2e-4, atol=2e-4)
+    assert rmse(ua, ub) <= 1e-4
+    assert a.prev_way_point_idx == b.prev_way_point_idx
