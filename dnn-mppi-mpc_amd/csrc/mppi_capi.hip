@@ -158,7 +158,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->traj_per_block = tpb;
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
-    h->n_part = h->fused ? fused_blocks(c.K) : h->n_blocks;
+    h->n_part = h->fused ? fused_blocks(c.K, c.T) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
     auto fail = [&](hipError_t e, const char *what) {

@@ -102,7 +102,7 @@ template <typename R> void launch_reduce(const KParams<R> &P, void *partials, in
 // rollout + cost + per-block softmin partial in one launch (T <= 128); fused_blocks(K) records
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s);
 bool fused_supported(int T);
-int fused_blocks(int K);
+int fused_blocks(int K, int T);
 // merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
 template <typename R>
 void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_f64, hipStream_t s);

@@ -323,6 +323,236 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParam
 }
 
 // ------------------------------------------------------------------------------------------
+// T <= 64: two samples per wave, two steps per lane.  Each 32-lane half of a wave owns one sample and
+// lane l of the half owns steps 2l and 2l+1, so ONE Philox4x32 call feeds both of its steps (words r0,r1
+// and r2,r3 -- the sampler's layout), the scans are 5 DPP steps over lane totals plus one add, and a
+// workgroup leaves one record per 32 samples (half as many for k_finalize to merge).  Same arithmetic per
+// step as Rollout::chunk; only the association of the prefix sums differs.
+// ------------------------------------------------------------------------------------------
+constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
+
+template <typename R, int MODEL>
+__global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const KParams<R> P, R *__restrict__ partials) {
+    __shared__ R sh_S[DUAL_SAMPLES];
+    __shared__ R sh_e[DUAL_SAMPLES];
+    __shared__ __attribute__((aligned(16))) R sh_acc[DUAL_SAMPLES][128];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+    STAMP(0);
+    const DevState sv = *P.st;  // one batch of scalar loads
+    const int k_start = sv.k_start;
+    if ((blockIdx.x + 1) * DUAL_SAMPLES <= k_start) return;  // every sample final: the old record stands
+    STAMP(1);
+    const int k = (blockIdx.x * DUAL_WAVES + wid) * 2 + h;    // this half's sample
+    const bool valid = k < P.K, live = valid && k >= k_start;
+    const int c = sv.c;
+    const unsigned iter = (unsigned)sv.iter;
+    const R *__restrict__ ref = P.ref;
+    const int T = P.T, t0 = 2 * l32, t1 = t0 + 1;
+    const bool a0 = t0 < T, a1 = t1 < T;
+
+    // ---- S1: this lane's noise for its two steps ---------------------------------------------------------
+    float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel>
+    STAMP(8);
+    if (valid && a0) {
+        if (P.use_philox) {
+            unsigned r[4];
+            px::philox4x32_10((unsigned)(k + P.k_offset), (unsigned)l32, iter, 0u, P.seed_lo, P.seed_hi, r);
+            px::box_muller(r[0], r[1], P.chol, e00, e01);
+            px::box_muller(r[2], r[3], P.chol, e10, e11);
+            if (!a1) { e10 = 0.f; e11 = 0.f; }
+        } else {
+            const float *pe = P.eps + ((size_t)k * T + t0) * 2;
+            const float2 ea = *reinterpret_cast<const float2 *>(pe);
+            e00 = ea.x;
+            e01 = ea.y;
+            if (a1) {
+                const float2 eb = *reinterpret_cast<const float2 *>(pe + 2);
+                e10 = eb.x;
+                e11 = eb.y;
+            }
+        }
+    }
+    STAMP(9);
+    R S_k = R(INFINITY);
+    if (__ballot(live) != 0ull) {  // at least one of the wave's two samples still needs its rollout
+        const bool exploit = (k + P.k_offset) < P.n_exploit;
+        R u00 = 0, u01 = 0, u10 = 0, u11 = 0;  // u<step><channel>
+        if (a0) { u00 = P.u[2 * t0]; u01 = P.u[2 * t0 + 1]; }
+        if (a1) { u10 = P.u[2 * t1]; u11 = P.u[2 * t1 + 1]; }
+        R v00 = exploit ? u00 + (R)e00 : (R)e00, v01 = exploit ? u01 + (R)e01 : (R)e01;  // :116-119
+        R v10 = exploit ? u10 + (R)e10 : (R)e10, v11 = exploit ? u11 + (R)e11 : (R)e11;
+        if (P.clamp_rollout) {  // `_g` :285-289
+            v00 = mf::clamp(v00, P.umax0); v01 = mf::clamp(v01, P.umax1);
+            v10 = mf::clamp(v10, P.umax0); v11 = mf::clamp(v11, P.umax1);
+        }
+        if (!a0) { v00 = 0; v01 = 0; }
+        if (!a1) { v10 = 0; v11 = 0; }
+
+        // ---- dynamics: scans over the lane totals of each half, then one add for the lane's second step ----
+        const R x_0 = (R)sv.x0[0], y_0 = (R)sv.x0[1], yaw_0 = (R)sv.x0[2];
+        R px0, py0, yw0, vl0 = 0, px1, py1, yw1, vl1 = 0;  // state after the lane's first / second step
+        if (MODEL == MODEL_DIFF) {  // :194-196
+            const R d0 = v01 * P.dt, d1 = v11 * P.dt;
+            const R yb0 = yaw_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(d0 + d1), R(0));
+            yw0 = yb0 + d0;
+            yw1 = yw0 + d1;
+            R s0, c0, s1, c1;
+            mf::sincos_(yb0, s0, c0);
+            mf::sincos_(yw0, s1, c1);
+            const R dx0 = v00 * c0 * P.dt, dx1 = v10 * c1 * P.dt, dy0 = v00 * s0 * P.dt, dy1 = v10 * s1 * P.dt;
+            px0 = x_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dx0 + dx1), R(0)) + dx0;
+            px1 = px0 + dx1;
+            py0 = y_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dy0 + dy1), R(0)) + dy0;
+            py1 = py0 + dy1;
+        } else {  // mppi_race_car.py:190-193, controls = [steer, accel]
+            const R vel_0 = (R)sv.x0[3];
+            const R dv0 = a0 ? v01 * P.dt : R(0), dv1 = a1 ? v11 * P.dt : R(0);
+            const R vb0 = vel_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dv0 + dv1), R(0));
+            vl0 = vb0 + dv0;
+            vl1 = vl0 + dv1;
+            const R dp0 = a0 ? vb0 / P.wheel_base * mf::tan_(v00) * P.dt : R(0);
+            const R dp1 = a1 ? vl0 / P.wheel_base * mf::tan_(v10) * P.dt : R(0);
+            const R yb0 = yaw_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dp0 + dp1), R(0));
+            yw0 = yb0 + dp0;
+            yw1 = yw0 + dp1;
+            R s0, c0, s1, c1;
+            mf::sincos_(yb0, s0, c0);
+            mf::sincos_(yw0, s1, c1);
+            const R dx0 = a0 ? vb0 * c0 * P.dt : R(0), dx1 = a1 ? vl0 * c1 * P.dt : R(0);
+            const R dy0 = a0 ? vb0 * s0 * P.dt : R(0), dy1 = a1 ? vl0 * s1 * P.dt : R(0);
+            px0 = x_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dx0 + dx1), R(0)) + dx0;
+            px1 = px0 + dx1;
+            py0 = y_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dy0 + dy1), R(0)) + dy0;
+            py1 = py0 + dy1;
+        }
+        STAMP(10);
+
+        // ---- waypoint index of the lane's two calls ---------------------------------------------------------
+        const int t_last = T - 1, lane_last = t_last >> 1, sub_last = t_last & 1;
+        int idx0 = c, idx1 = c, p_half = c, idx_term = c;  // p_half / idx_term: uniform within a half
+        if (!P.sequential) {
+            const int wlen = window_len<R>(P.window, P.n_ref, c);
+            idx0 = nearest_in_window(ref, c, wlen, px0, py0);
+            idx1 = nearest_in_window(ref, c, wlen, px1, py1);
+            idx_term = sub_last ? idx1 : idx0;  // meaningful on the lane that holds the last step
+        } else {
+            const int wlen = window_len<R>(P.window, P.n_ref, c);
+            const R d00 = dist2(ref, c, px0, py0), d01 = dist2(ref, c, px1, py1);
+            bool trig = false;
+#pragma unroll 4
+            for (int j = 1; j < wlen; ++j)
+                trig |= (a0 && dist2(ref, c + j, px0, py0) < d00) || (a1 && dist2(ref, c + j, px1, py1) < d01);
+            const unsigned long long m = __ballot(trig);
+            int p_a = c, p_b = c, term_a = c, term_b = c;
+            for (int hh = 0; hh < 2; ++hh) {  // rare: thread the index through that sample's calls in order
+                if (((hh ? (m >> 32) : m) & 0xffffffffull) == 0ull) continue;
+                int p = c;
+                for (int t = 0; t < T; ++t) {
+                    const int src = hh * 32 + (t >> 1);
+                    const R xt = (t & 1) ? wv::read_lane(px1, src) : wv::read_lane(px0, src);
+                    const R yt = (t & 1) ? wv::read_lane(py1, src) : wv::read_lane(py0, src);
+                    p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                    if (lane == src) { if (t & 1) idx1 = p; else idx0 = p; }
+                    if (t == t_last) {  // the terminal call moves the index once more (:244)
+                        p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                        if (hh) { term_b = p; p_b = p; } else { term_a = p; p_a = p; }
+                    }
+                }
+            }
+            p_half = h ? p_b : p_a;
+            idx_term = h ? term_b : term_a;
+        }
+        STAMP(11);
+
+        // ---- costs -----------------------------------------------------------------------------------------------
+        auto stage_cost = [&](R x, R y, R yaw, R vel, int idx, R ua, R ub, R va, R vb, bool &hit) {
+            hit = collided(P, x, y, yaw);
+            R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, idx, x, y, yaw, vel);
+            if (hit) st_c += P.penalty;
+            R ctrl;
+            if (MODEL == MODEL_DIFF) ctrl = (ua * P.sinv[0] + ub * P.sinv[2]) * va + (ua * P.sinv[1] + ub * P.sinv[3]) * vb;
+            else ctrl = ua * (P.sinv[0] * va + P.sinv[1] * vb) + ub * (P.sinv[2] * va + P.sinv[3] * vb);
+            return st_c + P.gamma * ctrl;
+        };
+        // state of the last step as held by lane_last of each half
+        const R lx = sub_last ? px1 : px0, ly = sub_last ? py1 : py0, lyaw = sub_last ? yw1 : yw0, lvel = sub_last ? vl1 : vl0;
+        R total;
+        if (P.accumulate) {
+            bool hit0, hit1;
+            const R st0 = stage_cost(px0, py0, yw0, vl0, idx0, u00, u01, v00, v01, hit0);
+            const R st1 = stage_cost(px1, py1, yw1, vl1, idx1, u10, u11, v10, v11, hit1);
+            const bool hit_l = sub_last ? hit1 : hit0;
+            R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
+            if (hit_l) term += P.penalty;
+            R acc_a = 0, acc_b = 0;
+            if (sizeof(R) == 4) {  // the reference's order of `S[k] += ...` (mppi_race_car.py:84), see Rollout::chunk
+                for (int t = 0; t < T; ++t) {
+                    const int src = t >> 1;
+                    acc_a += (t & 1) ? wv::read_lane(st1, src) : wv::read_lane(st0, src);
+                    acc_b += (t & 1) ? wv::read_lane(st1, 32 + src) : wv::read_lane(st0, 32 + src);
+                }
+            } else {
+                const R part = wv::scan_incl_half<wv::OpAdd>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
+                acc_a = wv::read_lane(part, 31);
+                acc_b = wv::read_lane(part, 63);
+            }
+            total = h ? acc_b + wv::read_lane(term, 32 + lane_last) : acc_a + wv::read_lane(term, lane_last);
+        } else {  // `S[k] =`: only the last step's stage cost survives (:124)
+            bool hit_l;
+            const int idx_l = sub_last ? idx1 : idx0;
+            const R st_l = stage_cost(lx, ly, lyaw, lvel, idx_l, sub_last ? u10 : u00, sub_last ? u11 : u01,
+                                      sub_last ? v10 : v00, sub_last ? v11 : v01, hit_l);
+            R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
+            if (hit_l) term += P.penalty;
+            const R both = st_l + term;
+            total = h ? wv::read_lane(both, 32 + lane_last) : wv::read_lane(both, lane_last);
+        }
+        S_k = total;
+        if (l32 == 0 && live) {
+            P.S[k] = total;
+            P.pout[k] = p_half;
+            if (P.sequential && p_half != c) atomicMin(&P.st->first_k, k);
+        }
+    }
+    if (valid && !live) S_k = P.S[k];  // final from an earlier speculation round
+    STAMP(2);
+
+    // ---- the workgroup's softmin record over its 32 samples (S5-S6) -----------------------------------------
+    const int sidx = wid * 2 + h;
+    if (l32 == 0) sh_S[sidx] = S_k;
+    __syncthreads();
+    STAMP(3);
+    const R rho = wv::read_lane(wv::scan_incl_half<wv::OpMin>(sh_S[l32]), 31);
+    const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
+    if (l32 == 0) sh_e[sidx] = e;
+    {
+        R *dst = &sh_acc[sidx][4 * l32];
+        dst[0] = e * (R)e00; dst[1] = e * (R)e01; dst[2] = e * (R)e10; dst[3] = e * (R)e11;
+    }
+    __syncthreads();
+    R *out = partials + (size_t)blockIdx.x * record_len(T, (int)sizeof(R));
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
+        R acc = 0;
+#pragma unroll
+        for (int q = 0; q < DUAL_SAMPLES; ++q) acc += sh_acc[q][i];
+        out[4 + i] = acc;
+    }
+    if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
+        R eta = 0, eta2 = 0;
+#pragma unroll
+        for (int q = 0; q < DUAL_SAMPLES; ++q) {
+            const R ew = sh_e[q];
+            eta += ew;
+            eta2 += ew * ew;
+        }
+        out[0] = rho;
+        out[1] = eta;
+        out[2] = eta2;
+    }
+    STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------
 // S5-S6: block-local softmin partials {rho_b, eta_b, eta2_b, W_b[T][2]}.
 // ------------------------------------------------------------------------------------------
 template <typename R>
@@ -881,14 +1111,28 @@ template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s) {
 }
 
 bool fused_supported(int T) { return T <= 128; }
-int fused_blocks(int K) { return (K + FUSED_WAVES - 1) / FUSED_WAVES; }
+// Two samples per wave pays once there are enough samples to keep >= 4 waves per SIMD with it (K >= 8192):
+// it issues ~45 % fewer instructions per sample but halves the number of waves, and at K = 4096 the
+// rollout is latency-bound (2 waves per SIMD cannot cover the ~10-cycle dependent-issue latency; measured
+// 5.7 us against 5.0 us for one sample per wave).  MPPI_DUAL=0/1 overrides for experiments.
+static bool dual_layout(int K, int T) {
+    if (T > 64) return false;
+    if (const char *e = getenv("MPPI_DUAL")) return atoi(e) != 0;
+    return K >= 8192;
+}
+int fused_blocks(int K, int T) {
+    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES;
+    return (K + per_block - 1) / per_block;
+}
 
 template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
-    const dim3 grid(fused_blocks(P.K)), block(64 * FUSED_WAVES);
-    if (P.T <= 64)
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, block, 0, s, P, partials);
+    const dim3 grid(fused_blocks(P.K, P.T));
+    if (dual_layout(P.K, P.T))
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL>), grid, dim3(64 * DUAL_WAVES), 0, s, P, partials);
+    else if (P.T <= 64)
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, dim3(64 * FUSED_WAVES), 0, s, P, partials);
     else
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, block, 0, s, P, partials);
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, dim3(64 * FUSED_WAVES), 0, s, P, partials);
 }
 
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s) {

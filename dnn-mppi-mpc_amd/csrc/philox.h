@@ -28,12 +28,8 @@ __device__ __forceinline__ float uniform_open(unsigned r) {  // (2*(r>>9)+1) * 2
     return (float)(2u * (r >> 9) + 1u) * 5.9604644775390625e-8f;
 }
 
-// eps[k_global, t, 0..1] ~ N(0, L L^T), chol = {L00, L10, L11}
-__device__ __forceinline__ void sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned k_global, int t,
-                                       const float (&chol)[3], float &e0, float &e1) {
-    unsigned r[4];
-    philox4x32_10(k_global, (unsigned)t >> 1, iter, 0u, seed_lo, seed_hi, r);
-    const unsigned ra = (t & 1) ? r[2] : r[0], rb = (t & 1) ? r[3] : r[1];
+// one Box-Muller pair from two Philox words, then the 2x2 Cholesky factor chol = {L00, L10, L11}
+__device__ __forceinline__ void box_muller(unsigned ra, unsigned rb, const float (&chol)[3], float &e0, float &e1) {
     // hardware log2 / sqrt (1 ulp each): the radius is good to ~3e-7 relative, far inside the sampler's
     // tolerance against its NumPy restatement, at 4 VALU ops instead of ~40
     const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(uniform_open(ra)));
@@ -42,6 +38,15 @@ __device__ __forceinline__ void sample(unsigned seed_lo, unsigned seed_hi, unsig
     const float z0 = rad * c, z1 = rad * s;
     e0 = chol[0] * z0;
     e1 = fmaf(chol[1], z0, chol[2] * z1);
+}
+
+// eps[k_global, t, 0..1] ~ N(0, L L^T), chol = {L00, L10, L11}
+__device__ __forceinline__ void sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned k_global, int t,
+                                       const float (&chol)[3], float &e0, float &e1) {
+    unsigned r[4];
+    philox4x32_10(k_global, (unsigned)t >> 1, iter, 0u, seed_lo, seed_hi, r);
+    const unsigned ra = (t & 1) ? r[2] : r[0], rb = (t & 1) ? r[3] : r[1];
+    box_muller(ra, rb, chol, e0, e1);
 }
 
 }  // namespace px

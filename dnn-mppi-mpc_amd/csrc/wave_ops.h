@@ -56,8 +56,25 @@ template <typename Op, typename R> __device__ __forceinline__ R scan_incl(R x) {
     return x;
 }
 
+// The same scan over each 32-lane half of the wave separately (two segments: lanes 0-31, 32-63).
+template <typename Op, typename R> __device__ __forceinline__ R scan_incl_half(R x) {
+    const R id = Op::template identity<R>();
+    x = Op::apply(x, dpp<DPP_ROW_SHR1>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR2>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR4>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR8>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_BCAST15, 0xA>(x, id));  // lane 15 -> row 1, lane 47 -> row 3
+    return x;
+}
+
 // lane i <- x[i-1], lane 0 <- carry.
 template <typename R> __device__ __forceinline__ R shift_up1(R x, R carry) { return dpp<DPP_WAVE_SHR1>(x, carry); }
+
+// lane i <- x[i-1] within each 32-lane half; the first lane of each half <- carry
+template <typename R> __device__ __forceinline__ R shift_up1_half(R x, R carry) {
+    const R sh = dpp<DPP_WAVE_SHR1>(x, carry);
+    return (lane_id() & 31) == 0 ? carry : sh;
+}
 
 __device__ __forceinline__ float read_lane(float x, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
