@@ -46,7 +46,8 @@ __device__ __forceinline__ void sincos_turns(float u, float &s, float &c) {
 
 __device__ __forceinline__ float tan_(float x) { return tanf(x); }
 __device__ __forceinline__ double tan_(double x) { return tan(x); }
-__device__ __forceinline__ float exp_(float x) { return expf(x); }
+// softmin weights exp(-beta (S - rho)) <= 1: the hardware exp2 path (2 ops, ~1e-6 relative) is ample for fp32 handles
+__device__ __forceinline__ float exp_(float x) { return __expf(x); }
 __device__ __forceinline__ double exp_(double x) { return exp(x); }
 
 // Python's float `%` with a positive divisor (mppi_race_car.py:141): result in [0, m).

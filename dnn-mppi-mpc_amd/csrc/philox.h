@@ -14,8 +14,10 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
                                               unsigned k1, unsigned (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: integer
+        // multiplies are quarter-rate, and the 40 of them were a third of the rollout's VALU time
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;

@@ -1,0 +1,126 @@
+"""GPU: ragged and degenerate shapes, both wave layouts, error behaviour at the boundary."""
+import numpy as np
+import pytest
+
+from oracle import mppi_oracle, philox
+
+pytestmark = pytest.mark.gpu
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, float) - np.asarray(b, float)) ** 2)))
+
+
+def dd_case(rng, K, T, n_ref, obstacles):
+    ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (rng.uniform(3, 10), rng.uniform(-5, 5)), n_ref)
+    kw = dict(delta_t=float(rng.choice([0.05, 0.1])), ref_path=ref, max_speed=float(rng.uniform(0.5, 5.0)),
+              max_omega=float(rng.uniform(0.3, 3.14)), num_samples_K=K, num_horizons_T=T,
+              param_exploration=float(rng.choice([0.0, 0.05, 0.3, 1.0])) or 0.02, param_lambda=float(rng.uniform(0.5, 20)),
+              param_alpha=float(rng.uniform(0.1, 0.99)),
+              sigma=np.array([[0.2, 0.03], [0.03, 0.05]]) if rng.random() < 0.5 else np.array([[0.1, 0.0], [0.0, 0.01]]),
+              stage_cost_weight=rng.uniform(1, 10, 3), terminal_cost_weight=rng.uniform(1, 10, 3),
+              visualize_optimal_traj=False, visualze_sampled_trajs=bool(rng.random() < 0.5))
+    if obstacles:
+        kw.update(obstacle_circles=np.column_stack([rng.uniform(0.5, 5, obstacles), rng.uniform(-3, 3, obstacles),
+                                                    rng.uniform(0.2, 0.6, obstacles)]), safety_margin_rate=0.8)
+    return kw
+
+
+@pytest.mark.parametrize("dual", ["0", "1"])
+@pytest.mark.parametrize("K,T,n_ref,obstacles", [(1, 10, 100, 0), (2, 11, 100, 0), (17, 10, 3, 0), (33, 25, 1, 2),
+                                                  (31, 64, 100, 1), (100, 33, 25, 0), (257, 50, 100, 3), (1000, 63, 7, 0)])
+def test_ragged_diffdrive_shapes_match_oracle(monkeypatch, dual, K, T, n_ref, obstacles):
+    """K not a multiple of the block size, odd horizons, paths shorter than the search window, both layouts."""
+    import dnn_mppi_mpc_amd as pkg
+    monkeypatch.setenv("MPPI_DUAL", dual)
+    rng = np.random.default_rng(K * 1000 + T)
+    kw = dd_case(rng, K, T, n_ref, obstacles)
+    eps = philox.sample_epsilon(kw["sigma"], K + T, 0, K, T)
+    x0 = np.array([rng.uniform(0, 1), rng.uniform(-0.5, 0.5), rng.uniform(-1, 1)])
+    u_in = rng.normal(0, 0.3, (T, 2))
+    o = mppi_oracle.DiffDriveOracle(**kw)
+    o.u_prev[:] = u_in
+    c = pkg.MPPIAlgorithms(**kw, precision="f64")
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: eps
+    for it in range(2):
+        ref = o.iteration(x0, eps.astype(np.float64))
+        u = c._calc_input_control(x0)[1]
+        S = c.sample_costs()
+        hit = ref["S"] > 1e9
+        np.testing.assert_array_equal(S > 1e9, hit)
+        np.testing.assert_allclose(S[~hit], ref["S"][~hit], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-7, atol=1e-9)
+        assert c.prev_way_point_idx == ref["idx_after"]
+        x0 = mppi_oracle.diffdrive_plant_step(x0, ref["u0_returned"], kw["delta_t"])
+
+
+@pytest.mark.parametrize("dual", ["0", "1"])
+@pytest.mark.parametrize("K,T", [(1, 5), (19, 5), (64, 64), (65, 63), (130, 30)])
+def test_ragged_racecar_shapes_match_oracle(monkeypatch, dual, K, T):
+    import dnn_mppi_mpc_amd as pkg
+    monkeypatch.setenv("MPPI_DUAL", dual)
+    lem = mppi_oracle.generate_lemniscate_racecar(60, 10.0)
+    kw = dict(ref_path=lem, horizon_step_T=T, number_of_samples_K=K, param_exploration=0.2, param_alpha=0.8,
+              param_lambda=30.0, visualize_optimal_traj=True, visualze_sampled_trajs=False)
+    sigma = np.array([[0.5, 0.0], [0.0, 0.1]])
+    eps = philox.sample_epsilon(sigma, K * T, 0, K, T)
+    o = mppi_oracle.RaceCarOracle(**kw)
+    c = pkg.MPPIRacecarController(**kw, precision="f32")
+    c._calc_epsilon = lambda *a, **k: eps
+    ref = o.iteration(lem[4], eps)
+    u = c._calc_control_input(lem[4])[1]
+    np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=3e-5, atol=1e-3)
+    assert rmse(u, ref["u_returned"]) <= 1e-4
+    assert c.prev_waypoints_idx == ref["idx_after"]
+
+
+def test_boundary_errors():
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    base = dict(model=capi.MODEL_DIFFDRIVE, K=64, T=20, delta_t=0.1, u_max=[1.0, 1.0], param_exploration=0.1,
+                param_lambda=1.0, param_alpha=0.5, sigma=[0.1, 0.0, 0.0, 0.1], stage_cost_weight=[1, 1, 1, 0],
+                terminal_cost_weight=[1, 1, 1, 0], search_window=20, filter_window=10, clamp_rollout=1)
+    e = pkg.Engine(**base)
+    with pytest.raises(pkg.MppiError) as ex:  # ref_path never set
+        e.step(np.zeros(3))
+    assert ex.value.code == capi.ERR_STATE
+    e.set_ref_path(mppi_oracle.generate_point_trajectory((0, 0), (1, 1), 10))
+    with pytest.raises(ValueError):  # wrong noise shape
+        e.step(np.zeros(3), torch.zeros(64, 19, 2, device="cuda"))
+    with pytest.raises(ValueError):  # wrong dtype
+        e.step(np.zeros(3), torch.zeros(64, 20, 2, device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):  # host tensor where a device tensor is required
+        e.step(np.zeros(3), torch.zeros(64, 20, 2))
+    with pytest.raises(pkg.MppiError) as ex:  # sequential index cannot be sharded
+        pkg.Engine(**dict(base, K=32, K_global=64, k_offset=0))
+    assert ex.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(pkg.MppiError) as ex:  # non-SPD sigma
+        pkg.Engine(**dict(base, sigma=[0.1, 0.5, 0.5, 0.1]))
+    assert ex.value.code == capi.ERR_BAD_ARG
+    with pytest.raises(pkg.MppiError) as ex:  # horizon below the filter window (the reference's filter raises)
+        pkg.Engine(**dict(base, T=9))
+    assert ex.value.code == capi.ERR_SHAPE
+    u, u0, st = e.step(np.zeros(3))  # and the handle still works after the failed calls
+    assert np.isfinite(u).all() and st.iteration == 1
+
+
+def test_checkpoint_resume_reproduces_the_run():
+    """u_prev + waypoint index + sampler iteration are the whole controller state."""
+    import dnn_mppi_mpc_amd as pkg
+    from test_gpu_engine import dd_kwargs
+    kw = dd_kwargs(512, 30)
+    a = pkg.MPPIAlgorithms(**kw, precision="f64", seed=11)
+    x = np.array([0.1, 0.0, -0.2])
+    for _ in range(4):
+        u0 = a._calc_input_control(x)[0].copy()
+        x = mppi_oracle.diffdrive_plant_step(x, u0, kw["delta_t"])
+    b = pkg.MPPIAlgorithms(**kw, precision="f64", seed=11)
+    b.u_prev[:] = a.u_prev
+    b.prev_way_point_idx = a.prev_way_point_idx
+    b._engine.set_iteration(4)
+    ua = a._calc_input_control(x)[1].copy()
+    ub = b._calc_input_control(x)[1].copy()
+    np.testing.assert_array_equal(ua, ub)
