@@ -24,6 +24,10 @@ struct mppi_handle {
     int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
+    std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
+    StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
+    long long seq = 0;
+    bool poll = true, idx_valid = true;
     MlpParams mlp;
     bool mlp_set = false;
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
@@ -182,8 +186,11 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMemset(h->d_partials2, 0, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
-    if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return fail(e, "hipHostMalloc(result)");
+    if ((e = hipHostGetDevicePointer((void **)&h->res_mapped, h->h_res, 0)) != hipSuccess)
+        return fail(e, "hipHostGetDevicePointer(result)");
+    h->poll = !getenv("MPPI_NO_POLL");
     if ((e = hipMemset(h->d_u, 0, r * 2 * c.T)) != hipSuccess) return fail(e, "hipMemset");        // u_prev = 0 (:82)
     if ((e = hipMemset(h->d_uhist, 0, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_S, 0, r * c.K)) != hipSuccess) return fail(e, "hipMemset");
@@ -228,6 +235,9 @@ extern "C" int mppi_set_ref_path(mppi_handle *h, const double *path, int32_t n, 
     h->d_ref = nullptr;
     HIPCHECK(h, hipMalloc(&h->d_ref, rsz(h) * 4 * n));
     h->n_ref = n;
+    h->ref_host = packed;
+    if (!h->f64)
+        for (double &v : h->ref_host) v = (double)(float)v;
     return upload_real(h, h->d_ref, packed.data(), packed.size());
 }
 
@@ -563,24 +573,71 @@ static void fill_stats(const mppi_handle *h, mppi_stats *stats) {
     stats->iteration = r->iter;
 }
 
+// The x0 call (mppi_differential_drive.py:96-99 / mppi_race_car.py:61): nearest waypoint of the observed state
+// in the window that starts at prev_way_point_idx, first minimum.  Same f64 arithmetic as k_set_state, on the
+// host so that the synchronous step needs no extra launch; the result travels as a kernel argument.
+static int host_x0_call(const mppi_handle *h, const double *x0) {
+    const int p = h->idx, n = h->n_ref, w = h->cfg.search_window;
+    int best_j = 0;
+    double best = INFINITY;
+    for (int j = 0; j < w && p + j < n; ++j) {
+        const double dx = x0[0] - h->ref_host[4 * (size_t)(p + j)], dy = x0[1] - h->ref_host[4 * (size_t)(p + j) + 1];
+        const double d = dx * dx + dy * dy;
+        if (d < best) { best = d; best_j = j; }
+    }
+    return p + best_j;
+}
+
+// wait for the result of the launches just enqueued: poll the completion word the finalize kernel writes into
+// mapped host memory (saves the device-to-host copy launch and the stream synchronisation), or copy + synchronise
+static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
+    if (seq) {
+        volatile long long *flag = &h->h_res->seq;
+        for (long long spins = 0; *flag != seq; ++spins) {
+            __builtin_ia32_pause();
+            if (spins > 200000000LL) {  // ~ seconds: something is wrong with the launch, surface the HIP error
+                HIPCHECK(h, hipStreamSynchronize(s));
+                HIPCHECK(h, hipGetLastError());
+                if (*flag != seq) FAIL(h, MPPI_ERR_HIP, "the finalize kernel never published its result");
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return MPPI_OK;
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(h, hipStreamSynchronize(s));
+    HIPCHECK(h, hipGetLastError());
+    return MPPI_OK;
+}
+
 template <typename R>
 static int step_impl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    launch_set_state<R>(P, x0, s);
+    const bool by_args = h->idx_valid && !getenv("MPPI_NO_ARGS");
+    if (by_args) {
+        P.use_args = F.use_args = 1;
+        P.c_arg = F.c_arg = host_x0_call(h, x0);
+        for (int i = 0; i < 4; ++i) P.x0_arg[i] = F.x0_arg[i] = x0[i];
+    } else {
+        launch_set_state<R>(P, x0, s);
+    }
+    if (h->poll) F.res = h->res_mapped;
     for (int round = 0;; ++round) {
+        F.seq = h->poll ? ++h->seq : 0;
         launch_slot<R>(h, P, F, s);
-        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
-        HIPCHECK(h, hipStreamSynchronize(s));
-        HIPCHECK(h, hipGetLastError());
+        int rc = wait_result(h, F.seq, s);
+        if (rc) return rc;
         if (h->h_res->status != STATUS_NEED_ROUND) break;
         if (round > h->cfg.K + 1) FAIL(h, MPPI_ERR_STATE, "waypoint speculation did not converge");
+        P.use_args = 0;  // repair rounds take the state the finalize kernel left in *st
     }
     h->dev_loop_primed = false;
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
     h->idx = h->h_res->idx_after;
+    h->idx_valid = true;
     fill_stats(h, stats);
     if (h->h_res->status == STATUS_PATH_END)
         FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
@@ -682,6 +739,7 @@ extern "C" int mppi_step_end_async(mppi_handle *h, const double *partials, int32
     else launch_back<float>(h, F, true, (hipStream_t)stream, h->slot_timed);
     HIPCHECK(h, hipGetLastError());
     h->begun = false;
+    h->idx_valid = false;  // the waypoint index now advances on the device until mppi_sync_result
     return MPPI_OK;
 }
 
@@ -692,6 +750,7 @@ extern "C" int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, m
     HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
     HIPCHECK(h, hipStreamSynchronize(s));
     h->idx = h->h_res->idx_after;
+    h->idx_valid = true;
     fill_stats(h, stats);
     if (h->h_res->status == STATUS_PATH_END)
         FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");

@@ -93,6 +93,16 @@ __device__ __forceinline__ R tracking_cost(const KParams<R> &P, const R (&w)[4],
 }
 
 
+// controller state of this launch: *st, with the observed state / x0 index overridden by kernel arguments
+template <typename R> __device__ __forceinline__ DevState load_state(const KParams<R> &P) {
+    DevState sv = *P.st;  // one batch of scalar loads
+    if (P.use_args) {
+        sv.x0[0] = P.x0_arg[0]; sv.x0[1] = P.x0_arg[1]; sv.x0[2] = P.x0_arg[2]; sv.x0[3] = P.x0_arg[3];
+        sv.c = P.c_arg;
+    }
+    return sv;
+}
+
 __device__ __forceinline__ bool round_unresolved(const DevState *st, int K) {
     const int fk = st->first_k;
     return fk != NO_TRIGGER && fk + 1 < K;

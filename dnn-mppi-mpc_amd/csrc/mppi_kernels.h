@@ -33,6 +33,7 @@ struct StepResult {
     double rho, eta, ess;
     double u0[2];
     double x_next[4];
+    long long seq;  // written LAST (after a system-scope fence) when the host polls mapped memory for completion
 };
 
 // Per-rank softmin partial of the split step (ABI layout): {rho, eta, eta2, W[T][2]} in doubles.
@@ -61,6 +62,10 @@ template <typename R> struct KParams {
     R *S;              // [K]
     int *pout;         // [K] waypoint index after sample k (sequential mode)
     DevState *st;
+    // synchronous step: the observed state and its nearest-waypoint index arrive as kernel arguments (the x0
+    // call, mppi_differential_drive.py:96-99, was made by the host side of the ABI) instead of through *st
+    int use_args, c_arg;
+    double x0_arg[4];
 };
 
 struct FinalizeParams {
@@ -75,8 +80,11 @@ struct FinalizeParams {
     const void *ref;         // [n_ref][4] kernel precision
     const int *pout;
     DevState *st;
-    StepResult *res;         // followed by 2*T doubles
+    StepResult *res;         // followed by 2*T doubles (device memory, or host memory mapped into the device)
     double *u0_trace;        // nullable: closed-loop trace [iter][2]
+    long long seq;           // != 0: publish res->seq = seq last, behind a system-scope fence (host polls it)
+    int use_args, c_arg;     // see KParams
+    double x0_arg[4];
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights

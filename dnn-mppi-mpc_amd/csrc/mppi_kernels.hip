@@ -239,7 +239,7 @@ template <typename R, int MODEL>
 __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-    const DevState sv = *P.st;  // one batch of scalar loads
+    const DevState sv = load_state(P);
     if (k >= P.K || k < sv.k_start) return;
     Rollout<R, MODEL> r(P, sv, k, lane);
     for (int ch = 0; ch < r.n_chunk; ++ch) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParam
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
     STAMP(0);
-    const DevState sv = *P.st;  // one batch of scalar loads
+    const DevState sv = load_state(P);
     const int k_start = sv.k_start;
     if ((blockIdx.x + 1) * FUSED_WAVES <= k_start) return;  // every sample final: the old partial stands
     STAMP(1);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const KParams<
     __shared__ __attribute__((aligned(16))) R sh_acc[DUAL_SAMPLES][128];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
     STAMP(0);
-    const DevState sv = *P.st;  // one batch of scalar loads
+    const DevState sv = load_state(P);
     const int k_start = sv.k_start;
     if ((blockIdx.x + 1) * DUAL_SAMPLES <= k_start) return;  // every sample final: the old record stands
     STAMP(1);
@@ -822,10 +822,22 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
 
     STAMP(16);
     // ---- loads that nothing below produces: state, this thread's u ----------------------------
-    const int fk = st->first_k, c_state = st->c, p_state = st->p, round = st->round;
-    const int idx_start = st->idx_start, path_end = st->path_end;
+    const int fk = st->first_k, round = st->round;
+    // first round of a synchronous step: the observed state and its x0 index came as kernel arguments
+    const bool args = F.use_args && round == 0;
+    const int c_state = args ? F.c_arg : st->c;
+    const int p_state = (args && !F.sequential) ? F.c_arg : st->p;  // update_prev_idx=True at x0 (mppi_race_car.py:61)
+    const int idx_start = args ? F.c_arg : st->idx_start, path_end = args ? (F.c_arg >= F.n_ref - 1) : st->path_end;
     const long long iter = st->iter;
-    const double x0v[4] = {st->x0[0], st->x0[1], st->x0[2], st->x0[3]};
+    const double x0v[4] = {args ? F.x0_arg[0] : st->x0[0], args ? F.x0_arg[1] : st->x0[1],
+                           args ? F.x0_arg[2] : st->x0[2], args ? F.x0_arg[3] : st->x0[3]};
+    auto publish = [&]() {  // completion word for a polling host: every result store first, system-wide
+        __syncthreads();
+        if (tid == 0 && F.seq) {
+            __threadfence_system();
+            *reinterpret_cast<volatile long long *>(&res->seq) = F.seq;
+        }
+    };
     const A u_old = tid < 2 * T ? u_dev[tid] : A(0);  // elements >= 256: re-read in the loops below
 
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
@@ -838,12 +850,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
                 st->c = c_new;
                 st->first_k = NO_TRIGGER;
                 st->round = round + 1;
+                if (args) {  // the repair rounds read the state from *st
+                    st->x0[0] = x0v[0]; st->x0[1] = x0v[1]; st->x0[2] = x0v[2]; st->x0[3] = x0v[3];
+                    st->idx_start = idx_start;
+                    st->path_end = path_end;
+                    st->p = p_state;
+                }
                 res->status = STATUS_NEED_ROUND;
                 res->k_next = fk + 1;
                 res->c_next = c_new;
                 res->rounds = round + 1;
                 res->iter = iter;
             }
+            publish();
             return;
         }
         c_final = c_new;
@@ -919,13 +938,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
         sh_u[i] = un;
     }
     __syncthreads();
-    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated
+    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
         if (tid == 0) {
             res->status = STATUS_PATH_END;
             res->idx_start = idx_start; res->idx_after = p_state; res->path_end = 1;
             res->rounds = round + 1; res->iter = iter;
-            st->first_k = NO_TRIGGER; st->k_start = 0;
+            st->first_k = NO_TRIGGER; st->k_start = 0; st->round = 0;
+            st->p = p_state;
         }
+        publish();
         return;
     }
     STAMP(19);
@@ -976,7 +997,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
             st->first_k = NO_TRIGGER;
             st->k_start = 0;
             st->round = 0;
-            if (F.sequential) st->p = c_final;
+            st->p = p_now;
+            if (args) {  // keep *st the single source of truth for every other entry point
+                st->x0[0] = x0v[0]; st->x0[1] = x0v[1]; st->x0[2] = x0v[2]; st->x0[3] = x0v[3];
+                st->c = c_state;
+                st->idx_start = idx_start;
+                st->path_end = path_end;
+            }
         }
         if (F.plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
             A best = A(INFINITY);
@@ -1003,6 +1030,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
             }
         }
     }
+    publish();
     STAMP(21);
 }
 
