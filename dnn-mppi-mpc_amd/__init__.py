@@ -11,5 +11,6 @@ from ._capi import MppiError, load_library
 from .build import build as build_library
 from .controllers import MPPIAlgorithms, MPPIRacecarController
 from .engine import Engine
+from . import paths
 
-__all__ = ["MPPIAlgorithms", "MPPIRacecarController", "Engine", "MppiError", "load_library", "build_library"]
+__all__ = ["MPPIAlgorithms", "MPPIRacecarController", "Engine", "MppiError", "load_library", "build_library", "paths"]

@@ -240,7 +240,7 @@ class MPPIAlgorithms(_ControllerBase):
                  param_lambda, param_alpha, sigma, stage_cost_weight, terminal_cost_weight, obstacle_circles=None,
                  safety_margin_rate=None, visualize_optimal_traj=True, visualze_sampled_trajs=True,
                  visualize_sampled_traj=None, *, variant="numpy", precision="f32", device=0, seed=0,
-                 process_group=None, waypoint_mode=None, learned_dynamics=None):
+                 process_group=None, waypoint_mode=None, learned_dynamics=None, learned_scalers=None):
         if visualize_sampled_traj is not None:  # the torch variant's spelling (:63-64)
             visualze_sampled_trajs = visualize_sampled_traj
         self.delta_t = _num(delta_t)
@@ -291,7 +291,7 @@ class MPPIAlgorithms(_ControllerBase):
         self._finish_init(cfg, ref_path, obstacle_circles, precision, device, seed, process_group)
         self._learned = learned_dynamics is not None
         if self._learned:
-            self._engine.set_mlp(learned_dynamics)
+            self._engine.set_mlp(learned_dynamics, learned_scalers)
 
     prev_way_point_idx = property(_ControllerBase._get_idx, _ControllerBase._set_idx)
 

@@ -25,7 +25,10 @@ namespace mppi {
 __device__ unsigned long long g_stamps[64];
 #define STAMP(n)                                                                 \
     do {                                                                         \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[n] = wall_clock64();   \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                               \
+            g_stamps[n] = wall_clock64();                                        \
+            if ((n) < 8) g_stamps[40 + (n)] = clock64(); /* shader clock ticks */ \
+        }                                                                        \
     } while (0)
 #else
 #define STAMP(n) \

@@ -73,14 +73,29 @@ class Engine:
         c = np.ascontiguousarray(circles, dtype=np.float64).reshape(-1, 3)
         self._ck(self.lib.mppi_set_obstacles(self._h, _dp(c), c.shape[0]))
 
-    def set_mlp(self, weights):
+    def set_mlp(self, weights, scalers=None):
         """Residual-model weights in the checkpoint's key layout (``state_dict`` of the reference's
-        ``MultiLayerPerceptron``, train/train_diff_mlp.py:13-36); tensors or arrays."""
+        ``MultiLayerPerceptron``, train/train_diff_mlp.py:13-36); tensors or arrays.
+
+        ``scalers``: optional dict with the ``StandardScaler`` statistics the model was trained with
+        (train/train_diff_mlp.py:72-86): ``in_mean``/``in_scale`` (5: state then control) and ``out_mean``/``out_scale``
+        (3).  The affine maps are folded into the first and last Linear on the host, so the kernel is unchanged:
+        MLP((z - m_in) / s_in) * s_out + m_out."""
         def arr(k):
             v = weights[k]
             if hasattr(v, "detach"):
                 v = v.detach().cpu().numpy()
             return np.ascontiguousarray(v, dtype=np.float32)
+        if scalers is not None:
+            weights = dict(weights)
+            f64 = lambda k: np.asarray(arr(k), np.float64)
+            m_in, s_in = np.asarray(scalers["in_mean"], np.float64), np.asarray(scalers["in_scale"], np.float64)
+            m_out, s_out = np.asarray(scalers["out_mean"], np.float64), np.asarray(scalers["out_scale"], np.float64)
+            w0, b0, wo, bo = f64("input_layer.weight"), f64("input_layer.bias"), f64("out_layer.weight"), f64("out_layer.bias")
+            weights["input_layer.weight"] = w0 / s_in[None, :]
+            weights["input_layer.bias"] = b0 - (w0 / s_in[None, :]) @ m_in
+            weights["out_layer.weight"] = wo * s_out[:, None]
+            weights["out_layer.bias"] = bo * s_out + m_out
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         n_hidden = sum(1 for k in weights if k.startswith("hidden_layer.") and k.endswith(".weight"))
         w_in, b_in = arr("input_layer.weight"), arr("input_layer.bias")

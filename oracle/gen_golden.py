@@ -263,3 +263,27 @@ if __name__ == "__main__":
         gen_diffdrive()
     if "rc" in which:
         gen_racecar()
+
+
+def gen_paths():
+    """Outputs of the reference's path generators (path_generator/*.py, the controllers' helpers)."""
+    from path_generator.cubic_spline_planner import calc_spline_course
+    from path_generator.bezierPath import calc_4points_bezier_path, calc_bezier_path
+    from controllers.mppi_differential_drive import generate_lemniscate_trajectory, generate_point_trajectory
+    from controllers.mppi_race_car import MPPIRacecarController as RC
+    from controllers.mppi_race_car_obstacle import MPPIRacecarController as RCObs
+    wx = np.array([0.0, 2.5, 5.0, 7.5, 3.0, -1.0])
+    wy = np.array([0.0, -3.0, 0.5, 4.0, 6.0, 2.0])
+    rx, ry, ryaw, rk, s = calc_spline_course(wx, wy, ds=0.07)
+    path4, cp4 = calc_4points_bezier_path(1.0, -2.0, 0.3, 8.0, 4.0, -1.2, 3.0)
+    cp = np.array([[0.0, 0.0], [2.0, 5.0], [6.0, -4.0], [9.0, 1.0], [12.0, 3.0]])
+    lem = generate_lemniscate_trajectory(7.5, 80)
+    pt = generate_point_trajectory(np.array([1.0, 2.0]), np.array([-4.0, 9.0]), 37)
+    save("paths", {}, dict(wx=wx, wy=wy, spline=np.array([rx, ry, ryaw, rk, s]), bez4=path4, bez4_cp=cp4, cp=cp,
+                           bez=calc_bezier_path(cp, 64), dd_lemniscate=np.array(lem), dd_point=np.array(pt),
+                           rc_lemniscate=RCObs().generate_lemniscate_trajectory(90, 12.0),
+                           rc_circle=RC().generate_simple_trajectory(70, 8.0)))
+
+
+if __name__ == "__main__" and "paths" in (sys.argv[1:] or ["paths"]):
+    gen_paths()

@@ -318,3 +318,35 @@ def test_learned_dynamics_zero_residual_equals_analytic_kernel():
     np.testing.assert_allclose(b.sample_costs(), a.sample_costs(), rtol=2e-4, atol=2e-4)
     assert rmse(ua, ub) <= 1e-4
     assert a.prev_way_point_idx == b.prev_way_point_idx
+
+
+def test_learned_dynamics_with_standard_scalers():
+    """The StandardScaler statistics of the reference's training pipeline (SURVEY.md App. C values) folded into
+    the first/last Linear: kernel output == oracle with explicitly scaled inputs/outputs."""
+    import dnn_mppi_mpc_amd as pkg
+    kw, w, eps = _mlp_case(512, 20, 4)
+    sc = dict(in_mean=np.array([4.390025834218122, -0.1261226463393075, -0.08013703690080425, 0.3585598113405002, -0.03134529264047761]),
+              in_scale=np.array([5.586594593004116, 3.6412154342302943, 1.0597377625187672, 1.0238108433208775, 1.8363768322750769]),
+              out_mean=np.array([-0.5611190600527631, 0.02943515716319776, -0.0151000663932475]) * 0.05,
+              out_scale=np.array([5.701096415279686, 3.590083579774014, 0.9961674472612329]) * 0.05)
+
+    class ScaledOracle(mppi_oracle.DiffDriveMlpOracle):
+        def rollout(self, x0, v):
+            K, T = v.shape[:2]
+            X = np.empty((K, T, 3))
+            s = np.tile(np.asarray(x0, np.float64), (K, 1))
+            for t in range(T):
+                z = (np.concatenate([s, v[:, t]], axis=1) - sc["in_mean"]) / sc["in_scale"]
+                r = mppi_oracle.mlp_forward(self.mlp_weights, z) * sc["out_scale"] + sc["out_mean"]
+                f = np.stack([v[:, t, 0] * np.cos(s[:, 2]), v[:, t, 0] * np.sin(s[:, 2]), v[:, t, 1]], axis=1)
+                s = s + self.delta_t * (f + r)
+                X[:, t] = s
+            return X
+
+    x0 = np.array([0.3, 0.2, 0.1])
+    ref = ScaledOracle(**kw, mlp_weights=w).iteration(x0, eps.astype(np.float64))
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, learned_scalers=sc)
+    c._calc_epsilon = lambda *a, **k: eps
+    u = c._calc_input_control(x0)[1]
+    np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=1e-3, atol=1e-3)
+    assert rmse(u, ref["u_returned"]) <= 1e-4

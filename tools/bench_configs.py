@@ -34,10 +34,18 @@ def marginal_rollout(eng, n):
 
 
 def report(name, K, T, eng, n, flop_per_step=None):
-    period, t_roll = marginal_rollout(eng, n)
+    period, t_marg = marginal_rollout(eng, n)
+    eng.enable_timing(True)  # in-situ duration of the rollout launch: event pair minus the empty-pair calibration
+    eng.run_closed_loop(n)
+    torch.cuda.synchronize()
+    kms = eng.last_kernel_ms()
+    eng.enable_timing(False)
+    t_roll = max(kms["rollout"] * 1e-3, 1e-9)
     alg = 16.0 * K * T + 8.0 * K
     out = {"config": name, "K": K, "T": T, "us_per_iter": 1e6 * period, "traj_steps_per_s": K * T / period,
-           "rollout_kernel_us": 1e6 * t_roll, "algorithmic_GBs": alg / t_roll / 1e9, "hbm_frac": alg / t_roll / 8e12}
+           "rollout_kernel_us": 1e6 * t_roll, "rollout_marginal_us": 1e6 * t_marg,
+           "other_launches_us": 1e3 * (kms["reduce"] + kms["finalize"]),
+           "algorithmic_GBs": alg / t_roll / 1e9, "hbm_frac": alg / t_roll / 8e12}
     if flop_per_step:
         out["TFLOPs"] = flop_per_step * K * T / t_roll / 1e12
         out["mfma_f32_frac"] = out["TFLOPs"] / 157.3
@@ -77,3 +85,12 @@ if "5" in which:
                            learned_dynamics=mo.random_mlp_weights(0), waypoint_mode="frozen")
     c._engine.set_state(np.zeros(3))
     report("5: diff-drive + residual MLP on MFMA", K, 50, c._engine, 10, flop_per_step=1581056.0)
+for tag, K in (("2x8", 32768), ("2x16", 65536), ("2x64", 262144)):
+    if tag in which:  # config 2's problem with more samples per launch: where the HBM roofline becomes reachable
+        c = pkg.MPPIAlgorithms(**dd, ref_path=mo.generate_point_trajectory((0, 0), (10, -5), 100), num_samples_K=K,
+                               num_horizons_T=50, param_exploration=0.0001, param_lambda=1.0, param_alpha=0.2,
+                               stage_cost_weight=np.array([5.0, 5.0, 10.0]), terminal_cost_weight=np.array([5.0, 5.0, 10.0]),
+                               waypoint_mode="frozen")  # no speculation rounds: every iteration is one rollout launch
+        c._engine.set_state(np.zeros(3))
+        c._engine.run_closed_loop(100)
+        report(f"2 scaled: diff-drive (frozen index), K={K}", K, 50, c._engine, 300)

@@ -39,3 +39,9 @@ for grp in ((0, 1, 8, 9, 10, 11, 2, 3, 4), (16, 17, 24, 25, 26, 18, 19, 20, 21))
     for g in grp:
         print(f"{names[g]:28s} +{np.median(acc[g]):8.0f} ns")
     print()
+# shader clock during the rollout kernel: s_memtime ticks per s_memrealtime tick (100 MHz)
+buf = (C.c_ulonglong * 64)()
+eng.run_closed_loop(1)
+lib.mppi_debug_stamps(buf, 64)
+dt_wall = (buf[4] - buf[0]) * 10e-9
+print(f"shader clock during k_rollout: {(buf[44] - buf[40]) / dt_wall / 1e6:.0f} MHz over {dt_wall*1e6:.2f} us")
