@@ -51,7 +51,13 @@ __device__ __forceinline__ float exp_(float x) { return __expf(x); }
 __device__ __forceinline__ double exp_(double x) { return exp(x); }
 
 // Python's float `%` with a positive divisor (mppi_race_car.py:141): result in [0, m).
-__device__ __forceinline__ float pymod(float a, float m) { const float r = fmodf(a, m); return r < 0.f ? r + m : r; }
+// fp32: a - m*floor(a/m) with one correction step instead of the exact iterative fmodf (a handful of ops instead of
+// ~60; it can differ from fmodf by an ulp of a, i.e. ~5e-7 rad on a wrapped yaw -- far inside the fp32 tolerance)
+__device__ __forceinline__ float pymod(float a, float m) {
+    float r = fmaf(-m, floorf(__fdividef(a, m)), a);
+    r = r < 0.f ? r + m : r;
+    return r >= m ? r - m : r;
+}
 __device__ __forceinline__ double pymod(double a, double m) { const double r = fmod(a, m); return r < 0.0 ? r + m : r; }
 
 template <typename R> __device__ __forceinline__ R clamp(R v, R lim) { return v < -lim ? -lim : (v > lim ? lim : v); }

@@ -34,6 +34,75 @@ __device__ __forceinline__ int nearest_in_window(const R *__restrict__ ref, int 
     return c + bj;
 }
 
+// ---- the same search with the window staged in LDS ------------------------------------------------------
+// The frozen-index modes search the SAME window ref[c .. c+wlen) for every step of every sample of a
+// workgroup (mppi_race_car.py:157-174: up to 200 candidates per call), so the window is copied to LDS once per
+// workgroup as pairs {x_2q, x_2q+1, y_2q, y_2q+1}: one broadcast 16/32-byte LDS read serves two candidates and the
+// distance arithmetic packs (v_pk_add / v_pk_mul / v_pk_fma), instead of a scalar load + address arithmetic
+// per candidate.  An odd window is padded with a far-away point that can never win.
+constexpr int WINDOW_LDS_MAX = 256;  // candidates
+
+template <typename R> struct alignas(16) RefPair { R x0, x1, y0, y1; };
+
+template <typename R>
+__device__ __forceinline__ void stage_window(RefPair<R> *sh, const R *__restrict__ ref, int c, int wlen, int tid,
+                                             int nthreads) {
+    const int npairs = (wlen + 1) >> 1;
+    for (int q = tid; q < npairs; q += nthreads) {
+        const int j0 = c + 2 * q, j1 = j0 + 1;
+        RefPair<R> r;
+        r.x0 = ref[4 * j0];
+        r.y0 = ref[4 * j0 + 1];
+        const bool has1 = 2 * q + 1 < wlen;
+        r.x1 = has1 ? ref[4 * j1] : R(1e30);
+        r.y1 = has1 ? ref[4 * j1 + 1] : R(1e30);
+        sh[q] = r;
+    }
+}
+
+template <typename R>
+__device__ __forceinline__ int nearest_in_window_lds(const RefPair<R> *sh, int c, int wlen, R x, R y) {
+    const int npairs = (wlen + 1) >> 1;
+    R best = R(INFINITY);
+    int bj = 0;
+#pragma unroll 4
+    for (int q = 0; q < npairs; ++q) {
+        const RefPair<R> r = sh[q];
+        const R dx0 = x - r.x0, dx1 = x - r.x1, dy0 = y - r.y0, dy1 = y - r.y1;
+        const R d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+        if (d0 < best) { best = d0; bj = 2 * q; }
+        if (d1 < best) { best = d1; bj = 2 * q + 1; }
+    }
+    return c + bj;
+}
+
+// Few active steps in this chunk (the tail of a horizon that is not a multiple of 64): `split` lanes share
+// one step's candidates (interleaved pairs), then combine with first-minimum semantics.  `split` is a power of
+// two <= 16 and n_act * split <= 64.  Returns, on lane t (< n_act), the index for step t.
+template <typename R>
+__device__ __forceinline__ int nearest_in_window_split(const RefPair<R> *sh, int c, int wlen, R x, R y, int split,
+                                                       int lane) {
+    const int lg = 31 - __clz(split);
+    const int src = lane >> lg, part = lane & (split - 1);
+    const R xs = __shfl(x, src), ys = __shfl(y, src);
+    const int npairs = (wlen + 1) >> 1;
+    R best = R(INFINITY);
+    int bj = 0x7fffffff;
+    for (int q = part; q < npairs; q += split) {
+        const RefPair<R> r = sh[q];
+        const R dx0 = xs - r.x0, dx1 = xs - r.x1, dy0 = ys - r.y0, dy1 = ys - r.y1;
+        const R d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+        if (d0 < best) { best = d0; bj = 2 * q; }
+        if (d1 < best) { best = d1; bj = 2 * q + 1; }
+    }
+    for (int m = 1; m < split; m <<= 1) {  // (smallest d, then smallest j) over the `split` lanes of a step
+        const R od = __shfl_xor(best, m);
+        const int oj = __shfl_xor(bj, m);
+        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; }
+    }
+    return c + __shfl(bj, lane << lg);  // lane t reads the result of its group's first lane
+}
+
 // Same search for ONE wave-uniform position with the candidates spread over the lanes.
 template <typename R>
 __device__ __forceinline__ int nearest_uniform(const R *__restrict__ ref, int c, int wlen, R x, R y, int lane) {
@@ -65,7 +134,7 @@ template <typename R> __device__ __forceinline__ bool collided(const KParams<R> 
         R sn, cs;
         mf::sincos_(yaw, sn, cs);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < 8; ++q) {  // the reference's 9th point repeats the 1st (mppi_race_car_obstacle.py:263-264)
             const R px = P.shape_x[q] * cs - P.shape_y[q] * sn + x;
             const R py = P.shape_x[q] * sn + P.shape_y[q] * cs + y;
             for (int m = 0; m < P.n_obs; ++m) {

@@ -90,12 +90,14 @@ template <typename R, int MODEL> struct Rollout {
     bool slow;             // sequential mode: some call moved the index, evolve it call by call
     R s_acc, s_last;
     const int n_chunk, lane_last;
+    const RefPair<R> *win;  // frozen-index modes: the search window staged in LDS by the workgroup (or null)
 
-    __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_)
+    __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_,
+                                       const RefPair<R> *win_ = nullptr)
         : P(P_), k(k_), lane(lane_), c(sv.c), iter((unsigned)sv.iter),
           exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)sv.x0[0]), cy((R)sv.x0[1]), cyaw((R)sv.x0[2]),
           cvel(MODEL == MODEL_RACE ? (R)sv.x0[3] : R(0)), p(sv.c), slow(false), s_acc(0), s_last(0),
-          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63) {}
+          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63), win(win_) {}
 
     // this lane's noise for step t of sample k (S1, or the caller's tensor)
     __device__ __forceinline__ void load_eps(int ch, float &e0, float &e1) const {
@@ -164,7 +166,17 @@ template <typename R, int MODEL> struct Rollout {
         // ---- waypoint index of every call in this chunk ----------------------------------
         int my_idx;
         if (!P.sequential) {
-            my_idx = nearest_in_window(ref, c, window_len<R>(P.window, P.n_ref, c), x, y);
+            const int wlen = window_len<R>(P.window, P.n_ref, c);
+            if (win) {
+                const int n_act = min(64, P.T - ch * 64);
+                int split = 1;  // a short tail chunk: several lanes share one step's candidates
+                while (split < 16 && 2 * split * n_act <= 64) split <<= 1;
+                my_idx = split > 1 ? nearest_in_window_split(win, c, wlen, x, y, split, lane)
+                                   : nearest_in_window_lds(win, c, wlen, x, y);
+                if (!act) my_idx = c;
+            } else {
+                my_idx = nearest_in_window(ref, c, wlen, x, y);
+            }
         } else {
             if (!slow) {  // does any call move the index away from p?
                 const int wlen = window_len<R>(P.window, P.n_ref, p);
@@ -243,8 +255,15 @@ __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
     const DevState sv = load_state(P);
+    __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
+    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    if (use_win) {
+        stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
     if (k >= P.K || k < sv.k_start) return;
-    Rollout<R, MODEL> r(P, sv, k, lane);
+    Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr);
     for (int ch = 0; ch < r.n_chunk; ++ch) {
         float e0, e1;
         r.chunk(ch, e0, e1);
@@ -271,12 +290,19 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParam
     if ((blockIdx.x + 1) * FUSED_WAVES <= k_start) return;  // every sample final: the old partial stands
     STAMP(1);
     const bool valid = k < P.K;
+    __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
+    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    if (use_win) {
+        stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
     float e0[NCH], e1[NCH];
     R S_k = R(INFINITY);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL> r(P, sv, k, lane);
+        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr);
         if (k >= k_start) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
@@ -352,6 +378,13 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const KParams<
     const R *__restrict__ ref = P.ref;
     const int T = P.T, t0 = 2 * l32, t1 = t0 + 1;
     const bool a0 = t0 < T, a1 = t1 < T;
+    __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    const int wlen0 = window_len<R>(P.window, P.n_ref, c);
+    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    if (use_win) {
+        stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
 
     // ---- S1: this lane's noise for its two steps ---------------------------------------------------------
     float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel>
@@ -435,8 +468,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const KParams<
         int idx0 = c, idx1 = c, p_half = c, idx_term = c;  // p_half / idx_term: uniform within a half
         if (!P.sequential) {
             const int wlen = window_len<R>(P.window, P.n_ref, c);
-            idx0 = nearest_in_window(ref, c, wlen, px0, py0);
-            idx1 = nearest_in_window(ref, c, wlen, px1, py1);
+            idx0 = use_win ? nearest_in_window_lds(sh_win, c, wlen, px0, py0) : nearest_in_window(ref, c, wlen, px0, py0);
+            idx1 = use_win ? nearest_in_window_lds(sh_win, c, wlen, px1, py1) : nearest_in_window(ref, c, wlen, px1, py1);
             idx_term = sub_last ? idx1 : idx0;  // meaningful on the lane that holds the last step
         } else {
             const int wlen = window_len<R>(P.window, P.n_ref, c);
