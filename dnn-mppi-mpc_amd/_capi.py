@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libmppi_hip.so")
+LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.so")  # MPPI_LIB: A/B a diagnostic build
 
 # enums of mppi_hip.h
 MODEL_DIFFDRIVE, MODEL_RACECAR, MODEL_DIFFDRIVE_MLP = 0, 1, 2
