@@ -169,6 +169,8 @@ def main():
         # passes in one launch (the noise stays in registers), so one launch owns the whole figure.
         alg_bytes = 16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES
         t_roll = t_rollout
+        if sharded:  # the sharded loop is paced by the collective and the host, so a repeated launch hides in the
+            t_roll = max(kms["rollout"] * 1e-3, 1e-9)  # slack: use the calibrated per-launch event pairs instead
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_file):  # rocprofv3 --pmc passes of this same command (see profiles/README.md)

@@ -191,14 +191,28 @@ class _ControllerBase:
     def run_closed_loop_sharded(self, n_iters):
         """n iterations with the driver's plant on the device and K sharded over the ranks; nothing but
         the all-gather leaves the GPU, one synchronisation at the end."""
+        import ctypes as C
+
         import torch
-        part, _ = self._exchange_buffers()
+        import torch.distributed as dist
+        part, gath = self._exchange_buffers()
         stream = torch.cuda.current_stream()
-        for _ in range(int(n_iters)):
-            self._engine.step_begin(None, None, part, stream)
-            gath = self._all_gather_partials()
-            self._engine.step_end_async(gath, self._world, stream)
-        u, u0, st = self._engine.sync_result(stream)
+        eng, lib = self._engine, self._engine.lib
+        h, sp = eng._h, C.c_void_p(stream.cuda_stream)
+        pp, gp = C.c_void_p(part.data_ptr()), C.c_void_p(gath.data_ptr())
+        nccl = dist.get_backend(self._pg) == "nccl"
+        for _ in range(int(n_iters)):  # per iteration: two ABI calls and the one collective
+            rc = lib.mppi_step_begin(h, None, None, pp, sp)
+            if rc:
+                eng._ck(rc)
+            if nccl:
+                dist.all_gather_into_tensor(gath, part, group=self._pg)
+            else:
+                exchange_partials(part, self._world, self._pg, out=gath)
+            rc = lib.mppi_step_end_async(h, gp, self._world, sp)
+            if rc:
+                eng._ck(rc)
+        u, u0, st = eng.sync_result(stream)
         self._u_host[...] = u
         self._u_dev_copy[...] = u
         self._idx_host = self._idx_dev = int(st.idx_after)
