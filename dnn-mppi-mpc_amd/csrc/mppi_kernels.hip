@@ -690,6 +690,24 @@ constexpr int MERGE_MAX_RECORDS = MERGE_GROUPS * MERGE_MAXJ;  // 256
 
 template <typename A> struct alignas(16) VecT { A v[16 / sizeof(A)]; };
 
+// LDS of the merge kernels.  w: the weighted noise in the filter's padded layout, [2 (T + W + 1)]
+// (k_merge: W = 0, plain); u: the updated controls [2T]; s: record scales; red: block reductions;
+// part: per-group partial sums.  Every region starts on a 16-byte boundary.
+__host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem) {
+    const size_t r4 = 3, nw = (2 * (size_t)(T + W + 1) + r4) & ~r4, nu = (2 * (size_t)T + r4) & ~r4;
+    return nw + nu + MERGE_MAX_RECORDS + 64 + (size_t)MERGE_GROUPS * 32 * (16 / elem);
+}
+template <typename A> struct MergeLds {
+    A *w, *u, *s, *red, *part;
+    __device__ __forceinline__ MergeLds(char *smem, int T, int W) {
+        w = reinterpret_cast<A *>(smem);
+        u = w + ((2 * (T + W + 1) + 3) & ~3);
+        s = u + ((2 * T + 3) & ~3);
+        red = s + MERGE_MAX_RECORDS;
+        part = red + 64;
+    }
+};
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fast_div(float a, float b) { return __fdividef(a, b); }
@@ -720,46 +738,78 @@ template <typename A> struct BlockRed {  // block-wide reductions through one LD
 };
 
 // Merge n <= 256 records with the rescale trick: rho = min rho_b,
-// s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  Result: W in sh_w[0, 2T);
-// rho/eta/eta2 in every thread.  Records come from a PREVIOUS launch: ordinary loads are coherent.
-// INTERNAL layout: thread (vector column vc, group grp) owns records grp*rpg .. grp*rpg+rpg-1 and reads
-// each one's 16-byte W vector; absent slots re-read record n-1 with a zero scale (unconditional loads,
-// static register indices).
+// s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  Records come from a PREVIOUS
+// launch: ordinary loads are coherent.  Written for latency -- the caller issues every load first thing
+// (merge_load_*), before it touches anything else, so that one memory round trip covers them all; the
+// heads are reduced per wave (each wave reads all 256 heads, DPP reductions, no block barrier).
+// INTERNAL layout: thread (vector column vc, group grp) owns records grp*32 .. grp*32+31 and reads each
+// one's 16-byte W vector.  Record b lives in slot b; slots >= n are never written by a producer and the
+// buffers are zero-filled and padded by 256 records at creation, so every load is unconditional and in
+// bounds, and an absent slot enters with a zero scale.
+template <typename A> struct MergeRegs {
+    VecT<A> w[MERGE_MAXJ];
+    A hr[4], he[4], he2[4];  // heads of records lane, lane+64, lane+128, lane+192
+};
+
 template <typename A>
-__device__ __forceinline__ void merge_internal(const A *__restrict__ recs, int n, int T, A beta, A *sh_w, A *sh_s,
-                                               A *sh_red, A *sh_part, A &rho, A &eta, A &eta2) {
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ recs, int T, MergeRegs<A> &m) {
+    const int lane = threadIdx.x & 63, rl = record_len(T, (int)sizeof(A));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const A *pb = recs + (unsigned)(lane + 64 * i) * (unsigned)rl;
+        m.hr[i] = pb[0];
+        m.he[i] = pb[1];
+        m.he2[i] = pb[2];
+    }
+}
+
+template <typename A>
+__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A> &m) {
+    constexpr int VW = 16 / sizeof(A);
+    const int tid = threadIdx.x, vc = tid & 31, grp = tid >> 5;
+    const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
+    const int nvc = (2 * T + VW - 1) / VW;  // 16-byte columns of W
+    const char *base = reinterpret_cast<const char *>(recs);
+    const unsigned off0 = (unsigned)(grp * MERGE_MAXJ) * rbytes +
+                          (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+#pragma unroll
+    for (int j = 0; j < MERGE_MAXJ; ++j)
+        m.w[j] = *reinterpret_cast<const VecT<A> *>(base + (off0 + (unsigned)j * rbytes));
+}
+
+// `store(i, v)` receives w_eps[i] = W[i] / eta for i in [0, 2T); rho/eta/eta2 end up in every thread.
+template <typename A, typename Store>
+__device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta, MergeRegs<A> &m,
+                                              A *sh_s, A *sh_part, A &rho, A &eta, A &eta2, Store store) {
     constexpr int VW = 16 / sizeof(A);
     using V = VecT<A>;
-    const int tid = threadIdx.x;
-    const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
-    const int vc = tid & 31, grp = tid >> 5;  // thread = (16-byte column, group of 32 consecutive records)
-    const int nvc = (2 * T + VW - 1) / VW;    // 16-byte columns of W
-    const char *base = reinterpret_cast<const char *>(recs);
-    A hr = A(INFINITY), he = 0, he2 = 0;
-    if (tid < n) {
-        const A *pb = reinterpret_cast<const A *>(base + (unsigned)tid * rbytes);
-        hr = pb[0];
-        he = pb[1];
-        he2 = pb[2];
-    }
-    // Record b lives in slot b (group b / 32); slots >= n are never written by a producer and the buffers
-    // are zero-filled and padded by 256 records at creation, so every load below is unconditional and in
-    // bounds, and an absent slot contributes 0 * 0.
-    V wv_[MERGE_MAXJ];
-    auto load_tile = [&](int vt) {
-        const unsigned off0 = (unsigned)(grp * MERGE_MAXJ) * rbytes + (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int vc = tid & 31, grp = tid >> 5;
+    const int nvc = (2 * T + VW - 1) / VW;
+    A lr = A(INFINITY);
 #pragma unroll
-        for (int j = 0; j < MERGE_MAXJ; ++j) wv_[j] = *reinterpret_cast<const V *>(base + (off0 + (unsigned)j * rbytes));
-    };
-    load_tile(0);
-    STAMP(24);
-    rho = BlockRed<A>::min1(hr, sh_red, tid);
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i >= n) m.hr[i] = A(INFINITY);
+        lr = fmin(lr, m.hr[i]);
+    }
+    rho = wv::reduce<wv::OpMin>(lr);
     STAMP(25);
-    const A sc = tid < n ? fast_exp(-beta * (hr - rho)) : A(0);
-    sh_s[tid] = sc;
-    eta = sc * he;
-    eta2 = sc * sc * he2;
-    BlockRed<A>::add2(eta, eta2, sh_red, tid);  // its barriers also publish sh_s
+    A sc[4];
+    eta = 0;
+    eta2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = lane + 64 * i < n ? fast_exp(-beta * (m.hr[i] - rho)) : A(0);
+        eta += sc[i] * m.he[i];
+        eta2 += sc[i] * sc[i] * m.he2[i];
+    }
+    eta = wv::reduce<wv::OpAdd>(eta);
+    eta2 = wv::reduce<wv::OpAdd>(eta2);
+    // this wave's threads use the scales of records 64 wid .. 64 wid + 63 only: a wave-local exchange
+    sh_s[tid] = wid == 0 ? sc[0] : wid == 1 ? sc[1] : wid == 2 ? sc[2] : sc[3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     STAMP(26);
     const A inv_eta = fast_div(A(1), eta);
     const int n_tiles = (nvc + 31) / 32;
@@ -771,28 +821,29 @@ __device__ __forceinline__ void merge_internal(const A *__restrict__ recs, int n
         for (int j = 0; j < MERGE_MAXJ; ++j) {
             const A sj = sh_s[grp * MERGE_MAXJ + j];
 #pragma unroll
-            for (int q = 0; q < VW; ++q) acc.v[q] += sj * wv_[j].v[q];
+            for (int q = 0; q < VW; ++q) acc.v[q] += sj * m.w[j].v[q];
         }
+        if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (vt + 1 < n_tiles) load_tile(vt + 1);
+        if (vt + 1 < n_tiles) merge_load_tile<A>(recs, T, vt + 1, m);
         for (int e = tid; e < 32 * VW; e += MERGE_THREADS) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
                 A t = 0;
 #pragma unroll
                 for (int g = 0; g < MERGE_GROUPS; ++g) t += sh_part[g * 32 * VW + e];
-                sh_w[i] = t * inv_eta;  // w_eps = W / eta, :132-135
+                store(i, t * inv_eta);  // w_eps = W / eta, :132-135
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // ABI layout (doubles, {rho, eta, eta2, W[2T]}), n = number of ranks: few records, plain loops.
-template <typename A>
-__device__ __forceinline__ void merge_abi(const double *__restrict__ recs, int n, int T, A beta, A *sh_w, A *sh_s,
-                                          A *sh_red, A &rho, A &eta, A &eta2) {
+template <typename A, typename Store>
+__device__ __forceinline__ void merge_abi(const double *__restrict__ recs, int n, int T, A beta, A *sh_s, A *sh_red,
+                                          A &rho, A &eta, A &eta2, Store store) {
     const int tid = threadIdx.x, plen = partial_len(T);
     A hr = A(INFINITY), he = 0, he2 = 0;
     if (tid < n) {
@@ -811,7 +862,7 @@ __device__ __forceinline__ void merge_abi(const double *__restrict__ recs, int n
     for (int i = tid; i < 2 * T; i += MERGE_THREADS) {
         A t = 0;
         for (int b = 0; b < n; ++b) t += sh_s[b] * (A)recs[b * plen + 3 + i];
-        sh_w[i] = t * inv_eta;  // w_eps = W / eta, :132-135
+        store(i, t * inv_eta);  // w_eps = W / eta, :132-135
     }
     __syncthreads();
 }
@@ -822,13 +873,16 @@ template <typename A, bool ABI_OUT>
 __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ recs, int n, int group, int T, A beta,
                                                          void *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    A *sh_w = reinterpret_cast<A *>(smem);
-    A *sh_s = sh_w + 4 * T, *sh_red = sh_s + MERGE_MAX_RECORDS, *sh_part = sh_red + 64;
+    const MergeLds<A> L(smem, T, 0);
+    A *sh_w = L.w;
     const int b0 = blockIdx.x * group, nb = min(group, n - b0);
+    const A *mine = recs + (size_t)b0 * record_len(T, (int)sizeof(A));
+    MergeRegs<A> mr;
+    merge_load_heads<A>(mine, T, mr);
+    merge_load_tile<A>(mine, T, 0, mr);
     A rho, eta, eta2;
-    merge_internal<A>(recs + (size_t)b0 * record_len(T, (int)sizeof(A)), nb, T, beta, sh_w, sh_s, sh_red, sh_part, rho,
-                      eta, eta2);
-    // merge_internal leaves W / eta; a record carries W itself
+    merge_combine<A>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
+    // merge_combine leaves W / eta; a record carries W itself
     if (ABI_OUT) {
         double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
         for (int i = threadIdx.x; i < 2 * T; i += MERGE_THREADS) o[3 + i] = (double)(sh_w[i] * eta);
@@ -843,13 +897,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
 template <typename A, bool ABI_RECS>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    A *sh_w = reinterpret_cast<A *>(smem);  // [2T] weighted noise, then filtered
-    A *sh_u = sh_w + 2 * F.T;               // [2T] updated u
-    A *sh_s = sh_u + 2 * F.T;               // [256] scale factors
-    A *sh_red = sh_s + MERGE_MAX_RECORDS;   // [64]
-    A *sh_part = sh_red + 64;               // [MERGE_GROUPS][128]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int T = F.T, W = F.filter_window, H = W / 2;
+    const MergeLds<A> L(smem, T, W);
+    A *sh_w = L.w;  // weighted noise in the filter's padded layout: sample t of channel d at [2 (t + H) + d]
+    A *sh_u = L.u;  // [2T] updated u
     DevState *st = F.st;
     StepResult *res = F.res;
     double *res_u = reinterpret_cast<double *>(res + 1);
@@ -857,16 +909,40 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
     const A *ref = reinterpret_cast<const A *>(F.ref);
 
     STAMP(16);
-    // ---- loads that nothing below produces: state, this thread's u ----------------------------
-    const int fk = st->first_k, round = st->round;
+    // ---- every load that nothing below produces, issued before anything waits: this thread's u, the
+    // records (their addresses depend on nothing but the kernel arguments) and the state as ONE batch of
+    // scalar loads -- a single memory round trip covers all of them
+    // (the state as one VECTOR load, lane i <- dword i: vector loads return in issue order, so it arrives
+    // before the records queued behind it; scalar loads would be issued after them and wait for the queue)
+    static_assert(sizeof(DevState) == 72, "DevState layout");
+    const int st_word = reinterpret_cast<const int *>(st)[lane < 18 ? lane : 0];
+    const A u_old = tid < 2 * T ? u_dev[tid] : A(0);  // elements >= 256: re-read in the loops below
+    MergeRegs<A> mr;
+    if (!ABI_RECS) {
+        merge_load_heads<A>(reinterpret_cast<const A *>(F.partials), T, mr);
+        merge_load_tile<A>(reinterpret_cast<const A *>(F.partials), T, 0, mr);
+    }
+    STAMP(24);
+    DevState sv;
+    {
+        auto word = [&](int i) { return __builtin_amdgcn_readlane(st_word, i); };
+        auto dbl = [&](int i) {
+            return __builtin_bit_cast(double, ((long long)word(i + 1) << 32) | (unsigned int)word(i));
+        };
+        sv.x0[0] = dbl(0); sv.x0[1] = dbl(2); sv.x0[2] = dbl(4); sv.x0[3] = dbl(6);
+        sv.p = word(8); sv.c = word(9); sv.k_start = word(10); sv.first_k = word(11);
+        sv.round = word(12); sv.path_end = word(13); sv.idx_start = word(14); sv.pad = 0;
+        sv.iter = ((long long)word(17) << 32) | (unsigned int)word(16);
+    }
+    const int fk = sv.first_k, round = sv.round;
     // first round of a synchronous step: the observed state and its x0 index came as kernel arguments
     const bool args = F.use_args && round == 0;
-    const int c_state = args ? F.c_arg : st->c;
-    const int p_state = (args && !F.sequential) ? F.c_arg : st->p;  // update_prev_idx=True at x0 (mppi_race_car.py:61)
-    const int idx_start = args ? F.c_arg : st->idx_start, path_end = args ? (F.c_arg >= F.n_ref - 1) : st->path_end;
-    const long long iter = st->iter;
-    const double x0v[4] = {args ? F.x0_arg[0] : st->x0[0], args ? F.x0_arg[1] : st->x0[1],
-                           args ? F.x0_arg[2] : st->x0[2], args ? F.x0_arg[3] : st->x0[3]};
+    const int c_state = args ? F.c_arg : sv.c;
+    const int p_state = (args && !F.sequential) ? F.c_arg : sv.p;  // update_prev_idx=True at x0 (mppi_race_car.py:61)
+    const int idx_start = args ? F.c_arg : sv.idx_start, path_end = args ? (F.c_arg >= F.n_ref - 1) : sv.path_end;
+    const long long iter = sv.iter;
+    const double x0v[4] = {args ? F.x0_arg[0] : sv.x0[0], args ? F.x0_arg[1] : sv.x0[1],
+                           args ? F.x0_arg[2] : sv.x0[2], args ? F.x0_arg[3] : sv.x0[3]};
     auto publish = [&]() {  // completion word for a polling host: every result store first, system-wide
         __syncthreads();
         if (tid == 0 && F.seq) {
@@ -874,7 +950,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
             *reinterpret_cast<volatile long long *>(&res->seq) = F.seq;
         }
     };
-    const A u_old = tid < 2 * T ? u_dev[tid] : A(0);  // elements >= 256: re-read in the loops below
 
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
@@ -912,61 +987,55 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
         cand_x = ref[4 * (p_now + lane)];
         cand_y = ref[4 * (p_now + lane) + 1];
     }
+    A sn_yaw = 0, cs_yaw = 1;  // the plant's trigonometry, while the loads are in flight
+    if (F.plant) mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
     STAMP(17);
 
+    // w_eps lands in the padded layout the filter reads: H leading and W - H trailing slots hold zeros
+    // (np.convolve 'same', mppi_differential_drive.py:257-263) or copies of the first / last H samples
+    // (mppi_race_car.py:211-222: the padded signal is xx[:H] + xx + xx[-H:])
+    const bool pad_copy = F.filter_mode == FILTER_RACE;
+    auto store_w = [&](int i, A v) {
+        const int t = i >> 1, d = i & 1;
+        const A pv = pad_copy ? v : A(0);
+        sh_w[2 * (t + H) + d] = v;
+        if (t < H) sh_w[2 * t + d] = pv;
+        if (t >= T - H) sh_w[2 * (t + 2 * H) + d] = pv;
+        if (t == T - 1) sh_w[2 * (T + 2 * H) + d] = pv;  // odd W only
+    };
     A rho, eta, eta2;
     if (ABI_RECS)
-        merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, sh_w, sh_s, sh_red, rho, eta,
-                     eta2);
+        merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
+                     store_w);
     else
-        merge_internal<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, sh_w, sh_s, sh_red, sh_part,
-                          rho, eta, eta2);
+        merge_combine<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
+                         eta2, store_w);
     STAMP(18);
 
-    // --- moving average of w_eps (window W) ------------------------------------------------------
+    // --- moving average of w_eps (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order ------
     const A inv_w = fast_div(A(1), (A)W);
     for (int i = tid; i < 2 * T; i += blockDim.x) {
         const int t = i >> 1, d = i & 1;
         A f;
-        // taps are read with a fully unrolled, predicated loop so the LDS reads issue back to back
-        constexpr int MAXW = 16;
-        if (F.filter_mode == FILTER_DIFF) {  // np.convolve(x, ones(W)/W, 'same'): taps t-H .. t+W-1-H
-            A sacc = 0;
-            if (W <= MAXW) {
-#pragma unroll
-                for (int q = 0; q < MAXW; ++q) {
-                    const int j = t + W - 1 - H - q;
-                    const A val = sh_w[2 * min(max(j, 0), T - 1) + d];
-                    sacc += (q < W && j >= 0 && j < T) ? val * inv_w : A(0);
-                }
-            } else {
-                for (int j = min(T - 1, t + W - 1 - H); j >= max(0, t - H); --j) sacc += sh_w[2 * j + d] * inv_w;
-            }
-            const int n_conv = (W + 1) / 2;  // mppi_differential_drive.py:265-269
-            if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
-            else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
-            if (t == T - 1)
-                for (int q = 1; q < n_conv; ++q) sacc *= fast_div((A)W, (A)(q + n_conv - (W % 2)));
-            f = sacc;
-        } else if (F.filter_mode == FILTER_RACE) {  // mppi_race_car.py:211-222
-            A sacc = 0;
-            if (W <= MAXW) {
-#pragma unroll
-                for (int q = 0; q < MAXW; ++q) {
-                    const int j = t + W - 1 - q;  // index into the padded signal
-                    const int src = j < H ? j : (j < T + H ? j - H : j - 2 * H);
-                    const A val = sh_w[2 * min(max(src, 0), T - 1) + d];
-                    sacc += q < W ? val * inv_w : A(0);
-                }
-            } else {
-                for (int j = t + W - 1; j >= t; --j) {
-                    const int src = j < H ? j : (j < T + H ? j - H : j - 2 * H);
-                    sacc += sh_w[2 * src + d] * inv_w;
-                }
-            }
-            f = sacc;
+        if (F.filter_mode == FILTER_NONE) {
+            f = sh_w[2 * (t + H) + d];
         } else {
-            f = sh_w[i];
+            const A *tap = sh_w + 2 * t + d;
+            A sacc = 0;
+            if (W == 10) {  // every reference variant; static LDS offsets, reads issue back to back
+#pragma unroll
+                for (int q = 0; q < 10; ++q) sacc += tap[2 * (9 - q)] * inv_w;
+            } else {
+                for (int q = 0; q < W; ++q) sacc += tap[2 * (W - 1 - q)] * inv_w;
+            }
+            if (F.filter_mode == FILTER_DIFF) {  // the edge factors of mppi_differential_drive.py:265-269
+                const int n_conv = (W + 1) / 2;
+                if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
+                else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
+                if (t == T - 1)
+                    for (int q = 1; q < n_conv; ++q) sacc *= fast_div((A)W, (A)(q + n_conv - (W % 2)));
+            }
+            f = sacc;
         }
         const A uo = i == tid ? u_old : u_dev[i];
         A un = uo + f;                                                        // u += w_epsilon, :141
@@ -1002,8 +1071,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
         const A u0a = sh_u[2 * (T > 1 ? 1 : 0)], u0b = sh_u[2 * (T > 1 ? 1 : 0) + 1];
         double xn[4] = {x0v[0], x0v[1], x0v[2], x0v[3]};
         if (F.plant) {  // the driver's plant with the returned control
-            A sn_yaw, cs_yaw;
-            mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
             if (F.model == MODEL_DIFF) {  // DifferentialDrive.update_state :33-40
                 xn[0] += (double)(u0a * cs_yaw) * F.dt;
                 xn[1] += (double)(u0a * sn_yaw) * F.dt;
@@ -1209,26 +1276,24 @@ template <typename R> void launch_reduce(const KParams<R> &P, void *partials, in
     hipLaunchKernelGGL(k_reduce<R>, dim3(n_blocks), dim3(256), shmem, s, P, (R *)partials);
 }
 
-static size_t merge_lds(int T, size_t elem) {
-    return elem * ((size_t)4 * T + MERGE_MAX_RECORDS + 64 + MERGE_GROUPS * 32 * (16 / elem) + 64);
-}
+static size_t merge_lds(int T, int W, size_t elem) { return elem * merge_lds_elems(T, W, elem); }
 
 template <typename R>
 void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_abi, hipStream_t s) {
     const int blocks = (n + group - 1) / group;
     if (out_abi)
-        hipLaunchKernelGGL((k_merge<R, true>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, sizeof(R)), s,
+        hipLaunchKernelGGL((k_merge<R, true>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, 0, sizeof(R)), s,
                            (const R *)recs, n, group, T, (R)beta, out);
     else
-        hipLaunchKernelGGL((k_merge<R, false>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, sizeof(R)), s,
+        hipLaunchKernelGGL((k_merge<R, false>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, 0, sizeof(R)), s,
                            (const R *)recs, n, group, T, (R)beta, out);
 }
 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
     if (abi_recs)
-        hipLaunchKernelGGL((k_finalize<R, true>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, sizeof(R)), s, F);
+        hipLaunchKernelGGL((k_finalize<R, true>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, F.filter_window, sizeof(R)), s, F);
     else
-        hipLaunchKernelGGL((k_finalize<R, false>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, sizeof(R)), s, F);
+        hipLaunchKernelGGL((k_finalize<R, false>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, F.filter_window, sizeof(R)), s, F);
 }
 
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {
