@@ -28,6 +28,7 @@ __device__ unsigned long long g_stamps[64];
         if (blockIdx.x == 0 && threadIdx.x == 0) {                               \
             g_stamps[n] = wall_clock64();                                        \
             if ((n) < 8) g_stamps[40 + (n)] = clock64(); /* shader clock ticks */ \
+            if ((n) == 16 || (n) == 21) g_stamps[32 + (n)] = clock64();           \
         }                                                                        \
     } while (0)
 #else

@@ -45,3 +45,5 @@ eng.run_closed_loop(1)
 lib.mppi_debug_stamps(buf, 64)
 dt_wall = (buf[4] - buf[0]) * 10e-9
 print(f"shader clock during k_rollout: {(buf[44] - buf[40]) / dt_wall / 1e6:.0f} MHz over {dt_wall*1e6:.2f} us")
+dt_fin = (buf[21] - buf[16]) * 10e-9
+print(f"shader clock during k_finalize: {(buf[53] - buf[48]) / dt_fin / 1e6:.0f} MHz over {dt_fin*1e6:.2f} us")
