@@ -82,13 +82,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # rehearsal of the N>1 path on a one-GPU box: every rank on MPPI_BENCH_DEVICE, gloo instead of RCCL (which
+    # needs one GPU per rank); the driver's runs set neither
+    if "MPPI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MPPI_BENCH_DEVICE"])
+    backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     pg = None
     sharded = world > 1 or bool(os.environ.get("MPPI_BENCH_FORCE_SHARDED"))  # rehearsal of the N>1 path on 1 GPU
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     import dnn_mppi_mpc_amd as pkg
@@ -117,7 +125,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     idx_timed = int(eng.stats.idx_after)
@@ -169,8 +177,8 @@ def main():
         # passes in one launch (the noise stays in registers), so one launch owns the whole figure.
         alg_bytes = 16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES
         t_roll = t_rollout
-        if sharded:  # the sharded loop is paced by the collective and the host, so a repeated launch hides in the
-            t_roll = max(kms["rollout"] * 1e-3, 1e-9)  # slack: use the calibrated per-launch event pairs instead
+        if sharded and ctrl.exchange != "p2p":  # paced by the collective and the host: a repeated launch hides in
+            t_roll = max(kms["rollout"] * 1e-3, 1e-9)  # the slack, use the calibrated per-launch event pairs instead
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_file):  # rocprofv3 --pmc passes of this same command (see profiles/README.md)
@@ -196,7 +204,9 @@ def main():
                                       "reference __main__ parameters, closed loop with the driver's plant on the device",
                           "K_per_gpu": K_SAMPLES, "K_global": K_SAMPLES * world, "T": HORIZON,
                           "waypoint_mode": "frozen (K-sharded)" if sharded else "sequential (reference-exact)",
-                          "noise": "Philox4x32-10 in-kernel", "waypoint_idx_during_timing": idx_timed},
+                          "noise": "Philox4x32-10 in-kernel", "waypoint_idx_during_timing": idx_timed,
+                          "exchange": {"none": "none (one GPU)", "p2p": "peer-to-peer stores + flags inside k_finalize",
+                                       "collective": "one all-gather per iteration (RCCL)"}[ctrl.exchange]},
                "iter_latency_us": 1e6 * dt / args.steps,
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "roofline": roof}

@@ -19,6 +19,7 @@ BETA_INV_EXPLORATION, BETA_INV_LAMBDA, BETA_LAMBDA = 0, 1, 2
 FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE = 0, 1, 2
 OBSTACLE_NONE, OBSTACLE_CIRCLE, OBSTACLE_OUTLINE = 0, 1, 2
 OK, ERR_BAD_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_PATH_END, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6, -7
+ERR_COMM = -8
 
 
 class MppiConfig(C.Structure):
@@ -73,6 +74,12 @@ PROTOTYPES = {
     "mppi_step_end": (C.c_int, [_H, C.c_void_p, C.c_int32, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_step_end_async": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
     "mppi_sync_result": (C.c_int, [_H, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
+    "mppi_comm_handle_bytes": (C.c_int, []),
+    "mppi_comm_export": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "mppi_comm_buffer": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "mppi_comm_connect": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_comm_probe": (C.c_int, [_H, C.c_void_p]),
+    "mppi_comm_close": (C.c_int, [_H]),
     "mppi_get_costs": (C.c_int, [_H, _D]),
     "mppi_get_weights": (C.c_int, [_H, _D]),
     "mppi_sample_epsilon": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -76,6 +76,56 @@ class _ControllerBase:
         self._partial = None
         self._gathered = None
         self.last_stats = None
+        self.exchange = "none" if self._world == 1 else "collective"
+        if self._world > 1:
+            self._setup_peer_exchange()
+
+    def _setup_peer_exchange(self):
+        """K sharded over several GPUs: wire the peer-to-peer exchange of the per-rank record (IPC-mapped
+        buffers + flags, include/mppi_hip.h `mppi_comm_*`) when every rank can; otherwise the iteration keeps
+        its one collective (RCCL all-gather).  ``MPPI_EXCHANGE=collective`` forces the latter."""
+        import os
+
+        import torch
+        import torch.distributed as dist
+        want = os.environ.get("MPPI_EXCHANGE", "p2p").lower()
+        if want not in ("p2p", "collective"):
+            raise ValueError("MPPI_EXCHANGE must be 'p2p' or 'collective'")
+        eng = self._engine
+        ok, handle = want == "p2p", b""
+        if ok:
+            try:
+                handle = eng.comm_export(self._world)
+            except capi.MppiError:
+                ok = False
+        cpu = dist.get_backend(self._pg) != "nccl"
+        flag_dev = "cpu" if cpu else f"cuda:{eng.cfg.device}"
+
+        def all_ok(v):  # every rank takes the same branch
+            t = torch.tensor([1 if v else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._pg)
+            return bool(t.item())
+
+        ok = all_ok(ok)
+        if ok:
+            handles = [None] * self._world
+            dist.all_gather_object(handles, handle, group=self._pg)
+            try:
+                eng.comm_connect(self._rank, handles)
+            except capi.MppiError:
+                ok = False
+            ok = all_ok(ok)
+        if ok:
+            dist.barrier(group=self._pg)
+            try:
+                eng.comm_probe()
+            except capi.MppiError:
+                ok = False
+            ok = all_ok(ok)
+        if ok:
+            self.exchange = "p2p"
+        elif handle:
+            eng.comm_close()
 
     # -- mutable attributes of the reference ---------------------------------------------------------
     @property
@@ -182,6 +232,8 @@ class _ControllerBase:
         """K sharded over the ranks of ``process_group``: one all-gather per iteration, every rank finishes
         the iteration identically."""
         import torch
+        if self.exchange == "p2p":  # the finalize kernel exchanges the records itself
+            return self._engine.step(x0, eps)
         part, _ = self._exchange_buffers()
         stream = torch.cuda.current_stream()
         self._engine.step_begin(x0, eps, part, stream)
@@ -195,6 +247,14 @@ class _ControllerBase:
 
         import torch
         import torch.distributed as dist
+        if self.exchange == "p2p":  # nothing leaves the GPUs until the last iteration is done
+            _, st = self._engine.run_closed_loop(int(n_iters))
+            u = self._engine.get_u_prev()
+            self._u_host[...] = u
+            self._u_dev_copy[...] = u
+            self._idx_host = self._idx_dev = int(st.idx_after)
+            self.last_stats = st
+            return st
         part, gath = self._exchange_buffers()
         stream = torch.cuda.current_stream()
         eng, lib = self._engine, self._engine.lib

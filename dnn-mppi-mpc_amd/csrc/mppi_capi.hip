@@ -46,6 +46,14 @@ struct mppi_handle {
     size_t ev_used = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
+    // peer-to-peer exchange (mppi_comm_*)
+    char *xbuf = nullptr;            // this rank's exchange buffer (fine-grained device memory)
+    size_t xbuf_bytes = 0;
+    int x_rank = 0, x_nranks = 0, x_export_nranks = 0;
+    std::vector<void *> x_opened;    // peers' buffers mapped through IPC handles
+    char **d_xpeers = nullptr;       // device array [x_nranks]
+    int *d_xerr = nullptr, *d_xok = nullptr;
+    long long xseq = 0, x_timeout = 300000000LL;
     std::string err;
 };
 
@@ -206,9 +214,12 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     return MPPI_OK;
 }
 
+extern "C" int mppi_comm_close(mppi_handle *h);
+
 extern "C" int mppi_destroy(mppi_handle *h) {
     if (!h) return MPPI_OK;
     hipSetDevice(h->cfg.device);
+    if (h->xbuf) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
                     h->d_w,   h->d_trace, h->d_st, h->d_res};
     for (void *b : bufs)
@@ -525,10 +536,21 @@ static void launch_back(mppi_handle *h, const FinalizeParams &F, bool abi_recs, 
     if (tm) hipEventRecord(next_event(h), s);
 }
 
+static void arm_exchange(mppi_handle *h, FinalizeParams &F) {
+    if (h->x_nranks <= 1) return;
+    F.x_nranks = h->x_nranks;
+    F.x_rank = h->x_rank;
+    F.x_seq = ++h->xseq;
+    F.x_timeout = h->x_timeout;
+    F.x_peers = h->d_xpeers;
+    F.x_err = h->d_xerr;
+}
+
 // rollout (-> reduce) -> finalize
 template <typename R>
 static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
     const bool tm = timing_on(h);
+    arm_exchange(h, F);
     launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part, tm);
     launch_back<R>(h, F, false, s, tm);
 }
@@ -639,6 +661,8 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
     h->idx = h->h_res->idx_after;
     h->idx_valid = true;
     fill_stats(h, stats);
+    if (h->h_res->status == STATUS_EXCHANGE_FAILED)
+        FAIL(h, MPPI_ERR_COMM, "peer-to-peer exchange: a rank did not arrive within the timeout");
     if (h->h_res->status == STATUS_PATH_END)
         FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
     h->iter = h->h_res->iter;
@@ -816,6 +840,111 @@ extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *samp
     return MPPI_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Peer-to-peer exchange of the per-rank softmin record (include/mppi_hip.h, mppi_comm_*)
+// ------------------------------------------------------------------------------------------
+extern "C" int mppi_comm_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int mppi_comm_close(mppi_handle *h) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (void *p : h->x_opened) hipIpcCloseMemHandle(p);
+    h->x_opened.clear();
+    if (h->d_xpeers) hipFree(h->d_xpeers);
+    if (h->d_xerr) hipFree(h->d_xerr);
+    if (h->d_xok) hipFree(h->d_xok);
+    if (h->xbuf) hipFree(h->xbuf);
+    h->d_xpeers = nullptr;
+    h->d_xerr = h->d_xok = nullptr;
+    h->xbuf = nullptr;
+    h->x_nranks = h->x_export_nranks = 0;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_comm_export(mppi_handle *h, int32_t nranks, void *handle_out) {
+    if (!h || !handle_out) return MPPI_ERR_BAD_ARG;
+    if (nranks < 2 || nranks > XCHG_MAX_RANKS)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_export: nranks must be 2..%d (got %d)", XCHG_MAX_RANKS, nranks);
+    if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "the exchange needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
+    if (h->xbuf) mppi_comm_close(h);
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    h->xbuf_bytes = 2 * xchg_slot_bytes(h->cfg.T, nranks);
+    // fine-grained: stores of a peer GPU become visible to this GPU's loads without a cache writeback here
+    HIPCHECK(h, hipExtMallocWithFlags((void **)&h->xbuf, h->xbuf_bytes, hipDeviceMallocFinegrained));
+    HIPCHECK(h, hipMemset(h->xbuf, 0, h->xbuf_bytes));
+    HIPCHECK(h, hipDeviceSynchronize());
+    hipIpcMemHandle_t ipc;
+    HIPCHECK(h, hipIpcGetMemHandle(&ipc, h->xbuf));
+    memcpy(handle_out, &ipc, sizeof(ipc));
+    h->x_export_nranks = nranks;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_comm_buffer(mppi_handle *h, void **device_ptr) {
+    if (!h || !device_ptr) return MPPI_ERR_BAD_ARG;
+    if (!h->xbuf) FAIL(h, MPPI_ERR_STATE, "mppi_comm_buffer before mppi_comm_export");
+    *device_ptr = h->xbuf;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_comm_connect(mppi_handle *h, int32_t rank, int32_t nranks, const void *handles,
+                                 void *const *local_ptrs) {
+    if (!h || (!handles && !local_ptrs)) return MPPI_ERR_BAD_ARG;
+    if (!h->xbuf || nranks != h->x_export_nranks)
+        FAIL(h, MPPI_ERR_STATE, "mppi_comm_connect: call mppi_comm_export with the same nranks first");
+    if (rank < 0 || rank >= nranks) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_connect: rank %d of %d", rank, nranks);
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    std::vector<char *> peers(nranks, nullptr);
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) {
+            peers[r] = h->xbuf;
+        } else if (local_ptrs && local_ptrs[r]) {
+            peers[r] = (char *)local_ptrs[r];
+        } else {
+            if (!handles) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_connect: no handle for rank %d", r);
+            hipIpcMemHandle_t ipc;
+            memcpy(&ipc, (const char *)handles + sizeof(ipc) * (size_t)r, sizeof(ipc));
+            void *p = nullptr;
+            HIPCHECK(h, hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess));
+            h->x_opened.push_back(p);
+            peers[r] = (char *)p;
+        }
+    }
+    HIPCHECK(h, hipMalloc((void **)&h->d_xpeers, sizeof(char *) * nranks));
+    HIPCHECK(h, hipMemcpy(h->d_xpeers, peers.data(), sizeof(char *) * nranks, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMalloc((void **)&h->d_xerr, sizeof(int)));
+    HIPCHECK(h, hipMalloc((void **)&h->d_xok, sizeof(int)));
+    HIPCHECK(h, hipMemset(h->d_xerr, 0, sizeof(int)));
+    if (const char *e = getenv("MPPI_EXCHANGE_TIMEOUT_MS")) {
+        const long long ms = atoll(e);
+        if (ms > 0) h->x_timeout = ms * 100000LL;  // the wall clock counts at 100 MHz
+    }
+    h->x_rank = rank;
+    h->x_nranks = nranks;
+    h->xseq = 0;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_comm_probe(mppi_handle *h, void *stream) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    if (h->x_nranks <= 1) FAIL(h, MPPI_ERR_STATE, "mppi_comm_probe before mppi_comm_connect");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    FinalizeParams F = make_finalize(h, nullptr, 0, 0);
+    arm_exchange(h, F);
+    launch_exchange_probe(F, h->d_xok, (hipStream_t)stream);
+    int ok = 0;
+    HIPCHECK(h, hipMemcpyAsync(&ok, h->d_xok, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHECK(h, hipStreamSynchronize((hipStream_t)stream));
+    if (!ok) {
+        HIPCHECK(h, hipMemset(h->d_xerr, 0, sizeof(int)));  // the caller may fall back and retry later
+        FAIL(h, MPPI_ERR_COMM, "peer-to-peer exchange probe: a rank did not arrive within the timeout");
+    }
+    return MPPI_OK;
+}
+
 template <typename R>
 static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, nullptr);
@@ -839,7 +968,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
         HIPCHECK(h, hipStreamSynchronize(s));
         HIPCHECK(h, hipGetLastError());
-        if (h->h_res->status == STATUS_PATH_END) break;
+        if (h->h_res->status == STATUS_PATH_END || h->h_res->status == STATUS_EXCHANGE_FAILED) break;
         done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
         if (++guard > h->cfg.K + 8) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
     }
@@ -847,6 +976,8 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     h->last_philox = true;
     h->idx = h->h_res->idx_after;
     fill_stats(h, stats);
+    if (h->h_res->status == STATUS_EXCHANGE_FAILED)
+        FAIL(h, MPPI_ERR_COMM, "peer-to-peer exchange: a rank did not arrive within the timeout");
     if (h->h_res->status == STATUS_PATH_END)
         FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
     if (u0_trace)

@@ -9,7 +9,16 @@ constexpr int MODEL_DIFF = 0, MODEL_RACE = 1;
 constexpr int OBS_NONE = 0, OBS_CIRCLE = 1, OBS_OUTLINE = 2;
 constexpr int FILTER_DIFF = 0, FILTER_RACE = 1, FILTER_NONE = 2;
 constexpr int NO_TRIGGER = 0x7fffffff;
-constexpr int STATUS_DONE = 0, STATUS_NEED_ROUND = 1, STATUS_PATH_END = 2;
+constexpr int STATUS_DONE = 0, STATUS_NEED_ROUND = 1, STATUS_PATH_END = 2, STATUS_EXCHANGE_FAILED = 3;
+
+// Peer-to-peer exchange buffer of one rank (mppi_comm_*), fine-grained device memory every rank maps:
+// two slots (iteration parity), each {long long flag[XCHG_MAX_RANKS]; double rec[nranks][xchg_rec_len(T)]}.
+// Rank r owns flag[r] / rec[r] of every buffer.
+constexpr int XCHG_MAX_RANKS = 64;
+__host__ __device__ inline int xchg_rec_len(int T) { return (3 + 2 * T + 1) & ~1; }
+__host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
+    return sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)nranks * xchg_rec_len(T);
+}
 
 // Controller state that lives on the device (so closed loops need no host round trip).
 struct DevState {
@@ -85,6 +94,14 @@ struct FinalizeParams {
     long long seq;           // != 0: publish res->seq = seq last, behind a system-scope fence (host polls it)
     int use_args, c_arg;     // see KParams
     double x0_arg[4];
+    // K sharded over GPUs with the records exchanged peer to peer: after merging its own block records the
+    // block stores this rank's record into slot (x_seq & 1) of EVERY rank's exchange buffer, raises its
+    // flag there to x_seq, waits for all flags in its own buffer and merges the x_nranks records
+    int x_nranks, x_rank;    // x_nranks <= 1: no exchange
+    long long x_seq;         // > 0, the same on every rank for the same iteration, increasing
+    long long x_timeout;     // 100 MHz ticks the wait may take before the iteration is abandoned
+    char *const *x_peers;    // device array [x_nranks]: every rank's exchange buffer (own one included)
+    int *x_err;              // sticky device flag: an exchange timed out, later slots return at once
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights
@@ -115,7 +132,10 @@ int fused_blocks(int K, int T);
 template <typename R>
 void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_f64, hipStream_t s);
 // F.partials holds n_part <= 256 records of precision R (recs_f64 false) or double
+// (with F.x_nranks > 1 and recs_f64 false: the peer-to-peer exchange variant)
 template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f64, hipStream_t s);
+// exchange self-test: one flag round over the peers, no records
+void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
                    float *eps_out, hipStream_t s);

@@ -843,9 +843,9 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
 
 // ABI layout (doubles, {rho, eta, eta2, W[2T]}), n = number of ranks: few records, plain loops.
 template <typename A, typename Store>
-__device__ __forceinline__ void merge_abi(const double *__restrict__ recs, int n, int T, A beta, A *sh_s, A *sh_red,
-                                          A &rho, A &eta, A &eta2, Store store) {
-    const int tid = threadIdx.x, plen = partial_len(T);
+__device__ __forceinline__ void merge_abi(const double *recs, int n, int T, A beta, A *sh_s, A *sh_red, A &rho, A &eta,
+                                          A &eta2, Store store, int stride = 0) {
+    const int tid = threadIdx.x, plen = stride ? stride : partial_len(T);
     A hr = A(INFINITY), he = 0, he2 = 0;
     if (tid < n) {
         const double *pb = recs + tid * plen;
@@ -895,8 +895,40 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     }
 }
 
-template <typename A, bool ABI_RECS>
+// raise this rank's flag in every rank's buffer (release: the records stored before the preceding barrier
+// are visible to whoever sees the flag), then wait for every rank's flag in the own buffer.  Returns false
+// after F.x_timeout ticks without them (and makes that sticky).  Every thread of the block calls this.
+__device__ __forceinline__ bool exchange_flags(const FinalizeParams &F, size_t slot_off) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid < F.x_nranks) {
+        long long *theirs = reinterpret_cast<long long *>(F.x_peers[tid] + slot_off) + F.x_rank;
+        __hip_atomic_store(theirs, F.x_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long *mine = reinterpret_cast<const long long *>(F.x_peers[F.x_rank] + slot_off) + tid;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != F.x_seq) {
+            if (wall_clock64() - t0 > (unsigned long long)F.x_timeout) {
+                __hip_atomic_store(F.x_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the records behind the flags
+    }
+    __syncthreads();
+    return __hip_atomic_load(F.x_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+__global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, int *ok_out) {
+    const bool ok = exchange_flags(F, (size_t)(F.x_seq & 1) * xchg_slot_bytes(F.T, F.x_nranks));
+    if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
+}
+
+// MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
+// caller (doubles, ABI layout); 2: block records + peer-to-peer exchange of the per-rank record
+template <typename A, int MODE>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams F) {
+    constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int T = F.T, W = F.filter_window, H = W / 2;
@@ -952,6 +984,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
         }
     };
 
+    if (XCHG && *reinterpret_cast<volatile int *>(F.x_err)) {  // an earlier exchange failed: do not wait again
+        if (tid == 0) { res->status = STATUS_EXCHANGE_FAILED; res->iter = iter; }
+        publish();
+        return;
+    }
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
     if (F.sequential && fk != NO_TRIGGER) {
@@ -1005,12 +1042,34 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
         if (t == T - 1) sh_w[2 * (T + 2 * H) + d] = pv;  // odd W only
     };
     A rho, eta, eta2;
-    if (ABI_RECS)
+    if (ABI_RECS) {
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
-    else
+    } else if (!XCHG) {
         merge_combine<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
                          eta2, store_w);
+    } else {
+        // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
+        merge_combine<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
+                         eta2, [&](int i, A v) { sh_u[i] = v; });
+        const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(T, F.x_nranks);
+        const size_t rec_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)F.x_rank * xchg_rec_len(T);
+        for (int p = 0; p < F.x_nranks; ++p) {
+            double *rec = reinterpret_cast<double *>(F.x_peers[p] + rec_off);
+            for (int i = tid; i < 2 * T; i += MERGE_THREADS) rec[3 + i] = (double)(sh_u[i] * eta);  // W itself
+            if (tid == 0) { rec[0] = (double)rho; rec[1] = (double)eta; rec[2] = (double)eta2; }
+        }
+        if (!exchange_flags(F, slot_off)) {  // a peer never arrived: nothing is updated
+            if (tid == 0) {
+                res->status = STATUS_EXCHANGE_FAILED;
+                res->rounds = round + 1; res->iter = iter;
+            }
+            publish();
+            return;
+        }
+        const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
+        merge_abi<A>(recs, F.x_nranks, T, (A)F.beta, L.s, L.red, rho, eta, eta2, store_w, xchg_rec_len(T));
+    }
     STAMP(18);
 
     // --- moving average of w_eps (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order ------
@@ -1291,10 +1350,14 @@ void launch_merge(const void *recs, int n, int group, int T, double beta, void *
 }
 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
-    if (abi_recs)
-        hipLaunchKernelGGL((k_finalize<R, true>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, F.filter_window, sizeof(R)), s, F);
-    else
-        hipLaunchKernelGGL((k_finalize<R, false>), dim3(1), dim3(MERGE_THREADS), merge_lds(F.T, F.filter_window, sizeof(R)), s, F);
+    const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R));
+    if (abi_recs) hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
+    else if (F.x_nranks > 1) hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
+    else hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
+}
+
+void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_exchange_probe, dim3(1), dim3(64), 0, s, F, ok_out);
 }
 
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {

@@ -181,6 +181,34 @@ class Engine:
         self._ck(self.lib.mppi_sync_result(self._h, _dp(u), _dp(u0), C.byref(self.stats), _stream_ptr(stream)))
         return u, u0, self.stats
 
+    # -- peer-to-peer exchange of the per-rank record (include/mppi_hip.h, mppi_comm_*) -------------------
+    def comm_export(self, nranks):
+        """Creates this rank's exchange buffer; returns its IPC handle (bytes) for the other ranks."""
+        buf = C.create_string_buffer(self.lib.mppi_comm_handle_bytes())
+        self._ck(self.lib.mppi_comm_export(self._h, int(nranks), buf))
+        return buf.raw
+
+    def comm_buffer(self):
+        p = C.c_void_p()
+        self._ck(self.lib.mppi_comm_buffer(self._h, C.byref(p)))
+        return p.value
+
+    def comm_connect(self, rank, handles, local_ptrs=None):
+        """``handles``: one IPC handle (bytes) per rank, in rank order (own entry ignored); ``local_ptrs``:
+        optional device addresses of peers living in this process (entries that are None use the handle)."""
+        n = len(handles)
+        blob = C.create_string_buffer(b"".join(bytes(hd) for hd in handles))
+        lp = None
+        if local_ptrs is not None:
+            lp = (C.c_void_p * n)(*[C.c_void_p(p) if p else C.c_void_p(None) for p in local_ptrs])
+        self._ck(self.lib.mppi_comm_connect(self._h, int(rank), n, blob, lp))
+
+    def comm_probe(self, stream=None):
+        self._ck(self.lib.mppi_comm_probe(self._h, _stream_ptr(stream)))
+
+    def comm_close(self):
+        self._ck(self.lib.mppi_comm_close(self._h))
+
     def step_end(self, partials, nranks, stream=None):
         u, u0 = np.empty((self.T, 2)), np.empty(2)
         self._ck(self.lib.mppi_step_end(self._h, _dev_ptr(partials), int(nranks), _dp(u), _dp(u0),

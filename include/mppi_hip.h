@@ -35,7 +35,8 @@ typedef enum {
     MPPI_ERR_HIP = -4,        /* a HIP runtime call failed */
     MPPI_ERR_PATH_END = -5,   /* race car: nearest waypoint is the last one (mppi_race_car.py:63-65) */
     MPPI_ERR_UNSUPPORTED = -6,/* e.g. sequential waypoint mode with K sharded over ranks */
-    MPPI_ERR_STATE = -7       /* call sequence error (step_end without step_begin ...) */
+    MPPI_ERR_STATE = -7,      /* call sequence error (step_end without step_begin ...) */
+    MPPI_ERR_COMM = -8        /* peer-to-peer exchange: a rank did not arrive within the timeout */
 } mppi_status;
 
 /* dynamics: controllers/mppi_differential_drive.py:182-198 / controllers/mppi_race_car.py:183-197 */
@@ -183,6 +184,28 @@ int mppi_step_end(mppi_handle *h, const double *partials, int32_t nranks, double
                   mppi_stats *stats, void *stream);
 int mppi_step_end_async(mppi_handle *h, const double *partials, int32_t nranks, void *stream);
 int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, mppi_stats *stats, void *stream);
+
+/*
+ * Peer-to-peer form of the same exchange ("direct P2P stores into peers' buffers +
+ * flag polling over xGMI" when the collective's latency dominates an iteration).  Every rank owns one
+ * exchange buffer in fine-grained device memory; `export` creates it and returns its IPC handle
+ * (mppi_comm_handle_bytes() bytes), the caller passes the handles of all ranks around once (any host
+ * channel, e.g. torch.distributed.all_gather_object) and `connect` maps them (entries of `local_ptrs`
+ * that are non-NULL are used as they are: peers living in the same process, see `mppi_comm_buffer`).
+ * From then on mppi_step and mppi_run_closed_loop exchange the per-rank record inside the finalize
+ * kernel: store into every peer's buffer, raise a flag, wait for all flags -- no host call and no
+ * collective launch per iteration.  Every rank must make the same sequence of step / closed-loop /
+ * probe calls.  A rank that does not arrive within MPPI_EXCHANGE_TIMEOUT_MS (default 3000) makes the
+ * call fail with MPPI_ERR_COMM on every rank; `probe` runs one flag round to check the wiring.
+ * Needs MPPI_WAYPOINT_FROZEN (as the split form does).
+ */
+int mppi_comm_handle_bytes(void);
+int mppi_comm_export(mppi_handle *h, int32_t nranks, void *handle_out);
+int mppi_comm_buffer(mppi_handle *h, void **device_ptr);
+int mppi_comm_connect(mppi_handle *h, int32_t rank, int32_t nranks, const void *handles /* [nranks][handle_bytes] */,
+                      void *const *local_ptrs /* nullable [nranks] */);
+int mppi_comm_probe(mppi_handle *h, void *stream);
+int mppi_comm_close(mppi_handle *h);
 
 /* S[K] of the last iteration (`S`, :103) and its weights (`_compute_weight`, :167-180); host doubles */
 int mppi_get_costs(mppi_handle *h, double *S);

@@ -1,6 +1,8 @@
-"""GPU (one box): two processes share cuda:0, each owns half of K; the product's sharded path
-(step_begin -> all-gather -> step_end, and the device closed loop) must equal one process with all of K.
-gloo carries the all-gather here (RCCL needs one GPU per rank); the kernels and the ABI are the real ones."""
+"""GPU (one box): two processes share cuda:0, each owns half of K; the product's sharded paths must equal one
+process with all of K -- with the one collective per iteration (step_begin -> all-gather -> step_end; gloo carries
+it here, RCCL needs one GPU per rank) and with the peer-to-peer exchange (IPC-mapped buffers, flags polled by the
+finalize kernel: the same code that runs over xGMI, here between two processes on one device).  The kernels and the
+ABI are the real ones."""
 import os
 import socket
 
@@ -25,7 +27,9 @@ def _kwargs(K):
                 visualze_sampled_trajs=False), lem
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange):
+    os.environ["MPPI_EXCHANGE"] = exchange
+    os.environ["MPPI_EXCHANGE_TIMEOUT_MS"] = "20000"
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,17 +45,18 @@ def _worker(rank, world, port, q):
             us.append(c._calc_control_input(lem[it].astype(np.float64))[1].copy())
         c._engine.set_state(lem[3].astype(np.float64))  # then the device closed loop, sharded
         c.run_closed_loop_sharded(4)
-        q.put((rank, np.stack(us), c.u_prev.copy(), c._engine.get_state(), int(c.last_stats.iteration)))
+        q.put((rank, np.stack(us), c.u_prev.copy(), c._engine.get_state(), int(c.last_stats.iteration), c.exchange))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_process_shards_equal_single_process():
+@pytest.mark.parametrize("exchange", ["collective", "p2p"])
+def test_two_process_shards_equal_single_process(exchange):
     import dnn_mppi_mpc_amd as pkg
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
@@ -64,7 +69,8 @@ def test_two_process_shards_equal_single_process():
     one._engine.set_state(lem[3].astype(np.float64))
     one._engine.run_closed_loop(4)
     u_loop, x_loop = one._engine.get_u_prev(), one._engine.get_state()
-    for rank, us_r, u_r, x_r, it_r in outs:
+    for rank, us_r, u_r, x_r, it_r, used in outs:
+        assert used == exchange
         np.testing.assert_allclose(us_r, us, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(u_r, u_loop, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(x_r, x_loop, rtol=1e-9, atol=1e-12)
