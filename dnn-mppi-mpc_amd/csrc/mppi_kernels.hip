@@ -919,9 +919,24 @@ __device__ __forceinline__ bool exchange_flags(const FinalizeParams &F, size_t s
     return __hip_atomic_load(F.x_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
+// wiring test: the full protocol of one iteration with a known pattern instead of a record (run it at least
+// four times, so that both slots are REUSED and a stale cached copy of a peer's stores would show)
 __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, int *ok_out) {
-    const bool ok = exchange_flags(F, (size_t)(F.x_seq & 1) * xchg_slot_bytes(F.T, F.x_nranks));
-    if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
+    const int tid = threadIdx.x, n_chk = 8;
+    const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(F.T, F.x_nranks);
+    const size_t recs_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS;
+    auto pattern = [&](int rank, int i) { return (double)(F.x_seq * 4096 + rank * 64 + i); };
+    for (int p = 0; p < F.x_nranks; ++p) {
+        double *rec = reinterpret_cast<double *>(F.x_peers[p] + recs_off) + (size_t)F.x_rank * xchg_rec_len(F.T);
+        if (tid < n_chk) rec[tid] = pattern(F.x_rank, tid);
+    }
+    bool ok = exchange_flags(F, slot_off);
+    const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + recs_off);
+    bool match = true;
+    for (int r = 0; r < F.x_nranks; ++r)
+        if (tid < n_chk) match &= recs[(size_t)r * xchg_rec_len(F.T) + tid] == pattern(r, tid);
+    ok = ok && __ballot(!match) == 0ull;
+    if (tid == 0) *ok_out = ok ? 1 : 0;
 }
 
 // MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
