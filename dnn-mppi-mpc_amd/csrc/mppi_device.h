@@ -163,8 +163,27 @@ __device__ __forceinline__ R tracking_cost(const KParams<R> &P, const R (&w)[4],
 
 
 // controller state of this launch: *st, with the observed state / x0 index overridden by kernel arguments
-template <typename R> __device__ __forceinline__ DevState load_state(const KParams<R> &P) {
-    DevState sv = *P.st;  // one batch of scalar loads
+// The controller state as ONE vector load (lane i <- dword i) + readlanes: a struct copy through scalar loads is
+// split by the compiler into dependent pieces (pointer, then the field the first branch needs, then the rest),
+// one memory round trip each.
+__device__ __forceinline__ DevState load_state_words(const DevState *st) {
+    static_assert(sizeof(DevState) == 72, "DevState layout");
+    const int lane = wv::lane_id();
+    const int w = reinterpret_cast<const int *>(st)[lane < 18 ? lane : 0];
+    auto word = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
+    auto dbl = [&](int i) { return __builtin_bit_cast(double, ((long long)word(i + 1) << 32) | (unsigned int)word(i)); };
+    DevState sv;
+    sv.x0[0] = dbl(0); sv.x0[1] = dbl(2); sv.x0[2] = dbl(4); sv.x0[3] = dbl(6);
+    sv.p = word(8); sv.c = word(9); sv.k_start = word(10); sv.first_k = word(11);
+    sv.round = word(12); sv.path_end = word(13); sv.idx_start = word(14); sv.pad = 0;
+    sv.iter = ((long long)word(17) << 32) | (unsigned int)word(16);
+    return sv;
+}
+
+// `st` = P.st; the hot kernels take it as their FIRST kernel argument as well, where the dispatcher preloads it
+// into SGPRs (-amdgpu-kernarg-preload-count), so that this load does not wait for the kernel-argument fetch
+template <typename R> __device__ __forceinline__ DevState load_state(const KParams<R> &P, const DevState *st) {
+    DevState sv = load_state_words(st);
     if (P.use_args) {
         sv.x0[0] = P.x0_arg[0]; sv.x0[1] = P.x0_arg[1]; sv.x0[2] = P.x0_arg[2]; sv.x0[3] = P.x0_arg[3];
         sv.c = P.c_arg;

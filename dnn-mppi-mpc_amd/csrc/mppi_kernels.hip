@@ -252,10 +252,10 @@ template <typename R, int MODEL> struct Rollout {
 
 // Any horizon: S[k] only (the softmin partials come from k_reduce).
 template <typename R, int MODEL>
-__global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
+__global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const KParams<R> P) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-    const DevState sv = load_state(P);
+    const DevState sv = load_state(P, st_pre);
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
@@ -279,16 +279,18 @@ __global__ __launch_bounds__(256) void k_rollout(const KParams<R> P) {
 constexpr int FUSED_WAVES = 16;
 
 template <typename R, int MODEL, int NCH>
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParams<R> P, R *__restrict__ partials) {
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevState *st_pre, const KParams<R> P,
+                                                                    R *__restrict__ partials) {
     __shared__ R sh_S[FUSED_WAVES];
     __shared__ R sh_e[FUSED_WAVES];
     __shared__ R sh_acc[FUSED_WAVES][128 * NCH];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
     STAMP(0);
-    const DevState sv = load_state(P);
+    const DevState sv = load_state(P, st_pre);
+    // (a workgroup whose samples are all final -- below k_start in a repair round -- rebuilds the same record from
+    // the stored costs; an early exit here would keep the compiler from fetching the kernel arguments up front)
     const int k_start = sv.k_start;
-    if ((blockIdx.x + 1) * FUSED_WAVES <= k_start) return;  // every sample final: the old partial stands
     STAMP(1);
     const bool valid = k < P.K;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
@@ -362,15 +364,15 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const KParam
 constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 
 template <typename R, int MODEL>
-__global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const KParams<R> P, R *__restrict__ partials) {
+__global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
+                                                                  R *__restrict__ partials) {
     __shared__ R sh_S[DUAL_SAMPLES];
     __shared__ R sh_e[DUAL_SAMPLES];
     __shared__ __attribute__((aligned(16))) R sh_acc[DUAL_SAMPLES][128];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
     STAMP(0);
-    const DevState sv = load_state(P);
-    const int k_start = sv.k_start;
-    if ((blockIdx.x + 1) * DUAL_SAMPLES <= k_start) return;  // every sample final: the old record stands
+    const DevState sv = load_state(P, st_pre);
+    const int k_start = sv.k_start;  // (no early exit for all-final workgroups, see k_rollout_fused)
     STAMP(1);
     const int k = (blockIdx.x * DUAL_WAVES + wid) * 2 + h;    // this half's sample
     const bool valid = k < P.K, live = valid && k >= k_start;
@@ -941,8 +943,11 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 
 // MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
 // caller (doubles, ABI layout); 2: block records + peer-to-peer exchange of the per-rank record
+// The leading arguments repeat F.partials, F.st, F.u and F.T: the dispatcher preloads them into SGPRs
+// (-amdgpu-kernarg-preload-count), so the first loads are issued without waiting for the kernel-argument fetch.
 template <typename A, int MODE>
-__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams F) {
+__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const DevState *st_pre,
+                                                            const void *u_pre, int T_pre, const FinalizeParams F) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -963,12 +968,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const FinalizeParams
     // (the state as one VECTOR load, lane i <- dword i: vector loads return in issue order, so it arrives
     // before the records queued behind it; scalar loads would be issued after them and wait for the queue)
     static_assert(sizeof(DevState) == 72, "DevState layout");
-    const int st_word = reinterpret_cast<const int *>(st)[lane < 18 ? lane : 0];
-    const A u_old = tid < 2 * T ? u_dev[tid] : A(0);  // elements >= 256: re-read in the loops below
+    const int st_word = reinterpret_cast<const int *>(st_pre)[lane < 18 ? lane : 0];
+    const A u_old = tid < 2 * T_pre ? reinterpret_cast<const A *>(u_pre)[tid] : A(0);  // elements >= 256: re-read below
     MergeRegs<A> mr;
     if (!ABI_RECS) {
-        merge_load_heads<A>(reinterpret_cast<const A *>(F.partials), T, mr);
-        merge_load_tile<A>(reinterpret_cast<const A *>(F.partials), T, 0, mr);
+        merge_load_heads<A>(reinterpret_cast<const A *>(partials_pre), T_pre, mr);
+        merge_load_tile<A>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
     STAMP(24);
     DevState sv;
@@ -1311,9 +1316,9 @@ template <typename R> void launch_set_state(const KParams<R> &P, const double *x
 template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s) {
     const int waves_per_block = 4, blocks = (P.K + waves_per_block - 1) / waves_per_block;
     if (P.model == MODEL_DIFF)
-        hipLaunchKernelGGL((k_rollout<R, MODEL_DIFF>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P);
+        hipLaunchKernelGGL((k_rollout<R, MODEL_DIFF>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P.st, P);
     else
-        hipLaunchKernelGGL((k_rollout<R, MODEL_RACE>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P);
+        hipLaunchKernelGGL((k_rollout<R, MODEL_RACE>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P.st, P);
 }
 
 bool fused_supported(int T) { return T <= 128; }
@@ -1334,11 +1339,11 @@ int fused_blocks(int K, int T) {
 template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
     const dim3 grid(fused_blocks(P.K, P.T));
     if (dual_layout(P.K, P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL>), grid, dim3(64 * DUAL_WAVES), 0, s, P, partials);
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (P.T <= 64)
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, dim3(64 * FUSED_WAVES), 0, s, P, partials);
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
     else
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, dim3(64 * FUSED_WAVES), 0, s, P, partials);
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
 }
 
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s) {
@@ -1366,9 +1371,13 @@ void launch_merge(const void *recs, int n, int group, int T, double beta, void *
 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
     const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R));
-    if (abi_recs) hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
-    else if (F.x_nranks > 1) hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
-    else hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F);
+    const DevState *st = F.st;
+    if (abi_recs)
+        hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
+    else if (F.x_nranks > 1)
+        hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
+    else
+        hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
 }
 
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
     float *ypart = zbuf + MLP_M * 8;         // [4][64][4] partial outputs of the last Linear per wave
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
-    const DevState sv = load_state(P);
+    const DevState sv = load_state(P, P.st);
     if (k0 + MLP_M <= sv.k_start) return;  // every sample of the tile is final: its record stands
     const bool valid = k < P.K, live = valid && k >= sv.k_start;
     const int c = sv.c;
