@@ -829,7 +829,7 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
         if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (vt + 1 < n_tiles) merge_load_tile<A>(recs, T, vt + 1, m);
+        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A>(recs, T, vt + 1, m);  // T > 64 only
         for (int e = tid; e < 32 * VW; e += MERGE_THREADS) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
