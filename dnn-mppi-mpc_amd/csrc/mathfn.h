@@ -61,5 +61,8 @@ __device__ __forceinline__ float pymod(float a, float m) {
 __device__ __forceinline__ double pymod(double a, double m) { const double r = fmod(a, m); return r < 0.0 ? r + m : r; }
 
 template <typename R> __device__ __forceinline__ R clamp(R v, R lim) { return v < -lim ? -lim : (v > lim ? lim : v); }
+template <> __device__ __forceinline__ float clamp<float>(float v, float lim) {  // one v_med3_f32
+    return __builtin_amdgcn_fmed3f(v, -lim, lim);
+}
 
 }  // namespace mf

@@ -34,7 +34,8 @@ __device__ __forceinline__ float uniform_open(unsigned r) {  // (2*(r>>9)+1) * 2
 __device__ __forceinline__ void box_muller(unsigned ra, unsigned rb, const float (&chol)[3], float &e0, float &e1) {
     // hardware log2 / sqrt (1 ulp each): the radius is good to ~3e-7 relative, far inside the sampler's
     // tolerance against its NumPy restatement, at 4 VALU ops instead of ~40
-    const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(uniform_open(ra)));
+    // (raw v_log_f32 = log2: the argument is in [2^-24, 1], never denormal, so the library's rescaling is dead weight)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(uniform_open(ra)));
     float s, c;
     mf::sincos_turns(uniform_open(rb), s, c);
     const float z0 = rad * c, z1 = rad * s;
