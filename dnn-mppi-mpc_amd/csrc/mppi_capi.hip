@@ -23,6 +23,7 @@ struct mppi_handle {
     bool fused = false;       // rollout + softmin partial in one launch (T <= 128)
     int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
+    void *d_heads = nullptr, *d_heads2 = nullptr;  // compact {rho, eta, eta2, 0} of d_partials / d_partials2
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
     std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
     StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
@@ -192,6 +193,10 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_partials2, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMalloc(partials2)");
     if ((e = hipMemset(h->d_partials, 0, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_partials2, 0, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMalloc(&h->d_heads, 32 * n1)) != hipSuccess) return fail(e, "hipMalloc(heads)");
+    if ((e = hipMalloc(&h->d_heads2, 32 * n2)) != hipSuccess) return fail(e, "hipMalloc(heads2)");
+    if ((e = hipMemset(h->d_heads, 0, 32 * n1)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_heads2, 0, 32 * n2)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
     if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
@@ -221,7 +226,7 @@ extern "C" int mppi_destroy(mppi_handle *h) {
     hipSetDevice(h->cfg.device);
     if (h->xbuf) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
-                    h->d_w,   h->d_trace, h->d_st, h->d_res};
+                    h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_res) hipHostFree(h->h_res);
@@ -437,6 +442,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.S = (R *)h->d_S;
     P.pout = h->d_pout;
     P.st = h->d_st;
+    P.heads = (R *)h->d_heads;
     return P;
 }
 
@@ -466,6 +472,7 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.umax0 = c.u_max[0];
     F.umax1 = c.u_max[1];
     F.partials = partials;
+    F.heads = partials == h->d_partials2 ? h->d_heads2 : h->d_heads;
     F.u = h->d_u;
     F.u_before = h->d_uhist;
     F.ref = h->d_ref;
@@ -505,7 +512,7 @@ static void launch_mlp(mppi_handle *, const KParams<double> &, hipStream_t) {}  
 
 template <typename R>
 static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipStream_t s, const void **recs,
-                         int *n_recs, bool tm) {
+                         const void **heads, int *n_recs, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
     const bool mlp = h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP;
     for (int rep = 0; rep < h->rollout_repeats; ++rep) {
@@ -517,11 +524,13 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     if (tm) hipEventRecord(next_event(h), s);
     if (!mlp && !h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
     *recs = h->d_partials;
+    *heads = h->d_heads;
     *n_recs = h->n_part;
     if (h->n_part > MAX_FINAL_PARTS) {
         const int group = h->n_part > 64 * MAX_FINAL_PARTS ? MAX_FINAL_PARTS : 64;
-        launch_merge<R>(h->d_partials, h->n_part, group, h->cfg.T, beta, h->d_partials2, false, s);
+        launch_merge<R>(h->d_partials, h->d_heads, h->n_part, group, h->cfg.T, beta, h->d_partials2, h->d_heads2, false, s);
         *recs = h->d_partials2;
+        *heads = h->d_heads2;
         *n_recs = (h->n_part + group - 1) / group;
     }
     if (tm) hipEventRecord(next_event(h), s);
@@ -551,7 +560,7 @@ template <typename R>
 static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
     const bool tm = timing_on(h);
     arm_exchange(h, F);
-    launch_front<R>(h, P, F.beta, s, &F.partials, &F.n_part, tm);
+    launch_front<R>(h, P, F.beta, s, &F.partials, &F.heads, &F.n_part, tm);
     launch_back<R>(h, F, false, s, tm);
 }
 
@@ -694,14 +703,14 @@ template <typename R>
 static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    const void *recs;
+    const void *recs, *heads;
     int n_recs;
     // closed loop on the device: the previous end_async already made the x0 call for the new state
     if (x0 || !h->dev_loop_primed) launch_set_state<R>(P, x0, s);
     h->dev_loop_primed = x0 == nullptr;
     h->slot_timed = timing_on(h);
-    launch_front<R>(h, P, F.beta, s, &recs, &n_recs, h->slot_timed);
-    launch_merge<R>(recs, n_recs, n_recs, h->cfg.T, F.beta, partial, true, s);  // this rank's single record (f64)
+    launch_front<R>(h, P, F.beta, s, &recs, &heads, &n_recs, h->slot_timed);
+    launch_merge<R>(recs, heads, n_recs, n_recs, h->cfg.T, F.beta, partial, nullptr, true, s);  // this rank's record (f64)
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;
     h->last_philox = eps == nullptr;

@@ -71,6 +71,8 @@ template <typename R> struct KParams {
     R *S;              // [K]
     int *pout;         // [K] waypoint index after sample k (sequential mode)
     DevState *st;
+    R *heads;          // [n records][4] {rho, eta, eta2, 0}: compact copy of the record heads, so that the merge
+                       // kernels read them coalesced (inside the records they sit 16 + 8T bytes apart)
     // synchronous step: the observed state and its nearest-waypoint index arrive as kernel arguments (the x0
     // call, mppi_differential_drive.py:96-99, was made by the host side of the ABI) instead of through *st
     int use_args, c_arg;
@@ -84,6 +86,7 @@ struct FinalizeParams {
     int window, is_f64, pad0, pad1;
     double beta, dt, wheel_base, umax0, umax1;
     const void *partials;    // [n_part][partial_len], n_part <= 256; element type: see launch_finalize
+    const void *heads;       // compact heads of `partials` (KParams::heads); unused for the ABI layout
     void *u;                 // [T][2] in the kernel precision (updated in place)
     void *u_before;          // copy of u before the update (for the viz rollouts)
     const void *ref;         // [n_ref][4] kernel precision
@@ -129,8 +132,10 @@ template <typename R> void launch_rollout_fused(const KParams<R> &P, void *parti
 bool fused_supported(int T);
 int fused_blocks(int K, int T);
 // merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
+// (`heads` / `out_heads`: the compact head arrays of the input / internal-layout output records)
 template <typename R>
-void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_f64, hipStream_t s);
+void launch_merge(const void *recs, const void *heads, int n, int group, int T, double beta, void *out, void *out_heads,
+                  bool out_f64, hipStream_t s);
 // F.partials holds n_part <= 256 records of precision R (recs_f64 false) or double
 // (with F.x_nranks > 1 and recs_f64 false: the peer-to-peer exchange variant)
 template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f64, hipStream_t s);

@@ -19,6 +19,8 @@
 
 namespace mppi {
 
+template <typename R> struct alignas(4 * sizeof(R)) VecT4 { R x, y, z, w; };
+
 // Diagnostic build only (make stamps): wall-clock stamps (s_memrealtime, 10 ns ticks) of block 0 / wave 0
 // at phase boundaries, written to a buffer nothing else reads.  The shipped library has no stamps.
 #ifdef MPPI_STAMPS
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, eta, eta2, R(0)};
     }
     STAMP(4);
 }
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, eta, eta2, R(0)};
     }
     STAMP(4);
 }
@@ -633,6 +637,7 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
         out[0] = rho;
         out[1] = a;
         out[2] = b;
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, a, b, R(0)};
     }
 
     // W_b[t] = sum_k e_k eps[k, t]  (:132-135 with the 1/eta factored out), lanes over t
@@ -755,14 +760,14 @@ template <typename A> struct MergeRegs {
 };
 
 template <typename A>
-__device__ __forceinline__ void merge_load_heads(const A *__restrict__ recs, int T, MergeRegs<A> &m) {
-    const int lane = threadIdx.x & 63, rl = record_len(T, (int)sizeof(A));
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A> &m) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const A *pb = recs + (unsigned)(lane + 64 * i) * (unsigned)rl;
-        m.hr[i] = pb[0];
-        m.he[i] = pb[1];
-        m.he2[i] = pb[2];
+    for (int i = 0; i < 4; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
+        const VecT4<A> hd = *reinterpret_cast<const VecT4<A> *>(heads + 4 * (size_t)(lane + 64 * i));
+        m.hr[i] = hd.x;
+        m.he[i] = hd.y;
+        m.he2[i] = hd.z;
     }
 }
 
@@ -873,15 +878,16 @@ __device__ __forceinline__ void merge_abi(const double *recs, int n, int T, A be
 // groups of `group` <= 256 internal records -> one record each: internal layout (large K) or the ABI
 // layout in doubles (the per-rank record of the split step)
 template <typename A, bool ABI_OUT>
-__global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ recs, int n, int group, int T, A beta,
-                                                         void *__restrict__ out) {
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ recs, const A *__restrict__ heads, int n,
+                                                         int group, int T, A beta, void *__restrict__ out,
+                                                         A *__restrict__ out_heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MergeLds<A> L(smem, T, 0);
     A *sh_w = L.w;
     const int b0 = blockIdx.x * group, nb = min(group, n - b0);
     const A *mine = recs + (size_t)b0 * record_len(T, (int)sizeof(A));
     MergeRegs<A> mr;
-    merge_load_heads<A>(mine, T, mr);
+    merge_load_heads<A>(heads + 4 * (size_t)b0, mr);
     merge_load_tile<A>(mine, T, 0, mr);
     A rho, eta, eta2;
     merge_combine<A>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
@@ -893,7 +899,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     } else {
         A *o = reinterpret_cast<A *>(out) + (size_t)blockIdx.x * record_len(T, (int)sizeof(A));
         for (int i = threadIdx.x; i < 2 * T; i += MERGE_THREADS) o[4 + i] = sh_w[i] * eta;
-        if (threadIdx.x == 0) { o[0] = rho; o[1] = eta; o[2] = eta2; }
+        if (threadIdx.x == 0) {
+            o[0] = rho; o[1] = eta; o[2] = eta2;
+            *reinterpret_cast<VecT4<A> *>(out_heads + 4 * (size_t)blockIdx.x) = VecT4<A>{rho, eta, eta2, A(0)};
+        }
     }
 }
 
@@ -943,11 +952,12 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 
 // MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
 // caller (doubles, ABI layout); 2: block records + peer-to-peer exchange of the per-rank record
-// The leading arguments repeat F.partials, F.st, F.u and F.T: the dispatcher preloads them into SGPRs
+// The leading arguments repeat F.partials, F.heads, F.st, F.u and F.T: the dispatcher preloads them into SGPRs
 // (-amdgpu-kernarg-preload-count), so the first loads are issued without waiting for the kernel-argument fetch.
 template <typename A, int MODE>
-__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const DevState *st_pre,
-                                                            const void *u_pre, int T_pre, const FinalizeParams F) {
+__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
+                                                            const DevState *st_pre, const void *u_pre, int T_pre,
+                                                            const FinalizeParams F) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -972,7 +982,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
     const A u_old = tid < 2 * T_pre ? reinterpret_cast<const A *>(u_pre)[tid] : A(0);  // elements >= 256: re-read below
     MergeRegs<A> mr;
     if (!ABI_RECS) {
-        merge_load_heads<A>(reinterpret_cast<const A *>(partials_pre), T_pre, mr);
+        merge_load_heads<A>(reinterpret_cast<const A *>(heads_pre), mr);
         merge_load_tile<A>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
     STAMP(24);
@@ -1359,25 +1369,26 @@ template <typename R> void launch_reduce(const KParams<R> &P, void *partials, in
 static size_t merge_lds(int T, int W, size_t elem) { return elem * merge_lds_elems(T, W, elem); }
 
 template <typename R>
-void launch_merge(const void *recs, int n, int group, int T, double beta, void *out, bool out_abi, hipStream_t s) {
+void launch_merge(const void *recs, const void *heads, int n, int group, int T, double beta, void *out, void *out_heads,
+                  bool out_abi, hipStream_t s) {
     const int blocks = (n + group - 1) / group;
     if (out_abi)
         hipLaunchKernelGGL((k_merge<R, true>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, 0, sizeof(R)), s,
-                           (const R *)recs, n, group, T, (R)beta, out);
+                           (const R *)recs, (const R *)heads, n, group, T, (R)beta, out, (R *)nullptr);
     else
         hipLaunchKernelGGL((k_merge<R, false>), dim3(blocks), dim3(MERGE_THREADS), merge_lds(T, 0, sizeof(R)), s,
-                           (const R *)recs, n, group, T, (R)beta, out);
+                           (const R *)recs, (const R *)heads, n, group, T, (R)beta, out, (R *)out_heads);
 }
 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
     const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R));
     const DevState *st = F.st;
     if (abi_recs)
-        hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
+        hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
     else if (F.x_nranks > 1)
-        hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
+        hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
     else
-        hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, st, (const void *)F.u, F.T, F);
+        hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
 }
 
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) {
@@ -1418,7 +1429,7 @@ extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
     template void launch_rollout<R>(const KParams<R> &, hipStream_t);                                     \
     template void launch_reduce<R>(const KParams<R> &, void *, int, hipStream_t);                         \
     template void launch_rollout_fused<R>(const KParams<R> &, void *, hipStream_t);                       \
-    template void launch_merge<R>(const void *, int, int, int, double, void *, bool, hipStream_t);        \
+    template void launch_merge<R>(const void *, const void *, int, int, int, double, void *, void *, bool, hipStream_t);        \
     template void launch_finalize<R>(const FinalizeParams &, bool, hipStream_t);                          \
     template void launch_weights<R>(const KParams<R> &, double, double, double *, hipStream_t);           \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);

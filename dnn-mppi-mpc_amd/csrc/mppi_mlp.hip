@@ -240,7 +240,11 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
         const float e = valid ? mf::exp_(-P.beta * (S - rho)) : 0.f;
         const float eta = wv::reduce<wv::OpAdd>(e), eta2 = wv::reduce<wv::OpAdd>(e * e);
         float *out = partials + (size_t)blockIdx.x * record_len(P.T, 4);
-        if (lane == 0) { out[0] = rho; out[1] = eta; out[2] = eta2; }
+        if (lane == 0) {
+            out[0] = rho; out[1] = eta; out[2] = eta2;
+            float *hd = P.heads + 4 * (size_t)blockIdx.x;  // the compact copy the merge kernels read
+            hd[0] = rho; hd[1] = eta; hd[2] = eta2; hd[3] = 0.f;
+        }
         for (int t = 0; t < P.T; ++t) {  // second pass over this tile's noise rows (regenerated / re-read)
             float e0 = 0.f, e1 = 0.f;
             if (valid) {
