@@ -474,10 +474,12 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.partials = partials;
     F.heads = partials == h->d_partials2 ? h->d_heads2 : h->d_heads;
     F.u = h->d_u;
+    F.u_out = h->d_u;
     F.u_before = h->d_uhist;
     F.ref = h->d_ref;
     F.pout = h->d_pout;
     F.st = h->d_st;
+    F.st_out = h->d_st;
     F.res = h->d_res;
     F.u0_trace = nullptr;
     return F;

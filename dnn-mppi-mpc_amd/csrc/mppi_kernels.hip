@@ -693,25 +693,30 @@ __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rh
 // {rho, eta, eta2, pad, W[2T] padded to a 16-byte multiple}, so W is read as aligned 16-byte vectors;
 // the per-rank record of the split step uses the ABI layout {rho, eta, eta2, W[2T]} in doubles.
 // ------------------------------------------------------------------------------------------
-constexpr int MERGE_THREADS = 256, MERGE_GROUPS = 8, MERGE_MAXJ = 32;
-constexpr int MERGE_MAX_RECORDS = MERGE_GROUPS * MERGE_MAXJ;  // 256
+constexpr int MERGE_THREADS = 256;
+constexpr int MERGE_MAX_RECORDS = 256;
+// NT threads merge 256 records: thread = (16-byte column vc = tid % 32, group grp = tid / 32), NT/32 groups of
+// 256/(NT/32) consecutive records.  NT = 256: the merge kernels' own launches; NT = 1024: the prologue of k_iter.
+template <int NT> struct MergeShape {
+    static constexpr int GROUPS = NT / 32, MAXJ = MERGE_MAX_RECORDS / GROUPS, WAVES = NT / 64;
+};
 
 template <typename A> struct alignas(16) VecT { A v[16 / sizeof(A)]; };
 
-// LDS of the merge kernels.  w: the weighted noise in the filter's padded layout, [2 (T + W + 1)]
-// (k_merge: W = 0, plain); u: the updated controls [2T]; s: record scales; red: block reductions;
-// part: per-group partial sums.  Every region starts on a 16-byte boundary.
-__host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem) {
+// LDS of the merge code.  w: the weighted noise in the filter's padded layout, [2 (T + W + 1)] (k_merge: W = 0,
+// plain); u: the updated controls [2T]; s: 64 record scales per wave; red: block reductions; part: per-group
+// partial sums.  Every region starts on a 16-byte boundary.
+__host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem, int nt = MERGE_THREADS) {
     const size_t r4 = 3, nw = (2 * (size_t)(T + W + 1) + r4) & ~r4, nu = (2 * (size_t)T + r4) & ~r4;
-    return nw + nu + MERGE_MAX_RECORDS + 64 + (size_t)MERGE_GROUPS * 32 * (16 / elem);
+    return nw + nu + (size_t)nt + 64 + (size_t)(nt / 32) * 32 * (16 / elem);
 }
-template <typename A> struct MergeLds {
+template <typename A, int NT = MERGE_THREADS> struct MergeLds {
     A *w, *u, *s, *red, *part;
     __device__ __forceinline__ MergeLds(char *smem, int T, int W) {
         w = reinterpret_cast<A *>(smem);
         u = w + ((2 * (T + W + 1) + 3) & ~3);
         s = u + ((2 * T + 3) & ~3);
-        red = s + MERGE_MAX_RECORDS;
+        red = s + NT;
         part = red + 64;
     }
 };
@@ -721,7 +726,7 @@ __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fast_div(float a, float b) { return __fdividef(a, b); }
 __device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
 
-template <typename A> struct BlockRed {  // block-wide reductions through one LDS exchange each
+template <typename A> struct BlockRed {  // block-wide reductions through one LDS exchange each (256 threads)
     static __device__ __forceinline__ A min1(A v, A *sh, int tid) {
         v = wv::reduce<wv::OpMin>(v);
         __syncthreads();
@@ -750,17 +755,16 @@ template <typename A> struct BlockRed {  // block-wide reductions through one LD
 // launch: ordinary loads are coherent.  Written for latency -- the caller issues every load first thing
 // (merge_load_*), before it touches anything else, so that one memory round trip covers them all; the
 // heads are reduced per wave (each wave reads all 256 heads, DPP reductions, no block barrier).
-// INTERNAL layout: thread (vector column vc, group grp) owns records grp*32 .. grp*32+31 and reads each
-// one's 16-byte W vector.  Record b lives in slot b; slots >= n are never written by a producer and the
-// buffers are zero-filled and padded by 256 records at creation, so every load is unconditional and in
-// bounds, and an absent slot enters with a zero scale.
-template <typename A> struct MergeRegs {
-    VecT<A> w[MERGE_MAXJ];
+// Record b lives in slot b; slots >= n are never written by a producer and the buffers are zero-filled and
+// padded by 256 records at creation, so every load is unconditional and in bounds, and an absent slot enters
+// with a zero scale.
+template <typename A, int NT = MERGE_THREADS> struct MergeRegs {
+    VecT<A> w[MergeShape<NT>::MAXJ];
     A hr[4], he[4], he2[4];  // heads of records lane, lane+64, lane+128, lane+192
 };
 
-template <typename A>
-__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A> &m) {
+template <typename A, int NT>
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT> &m) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
@@ -771,25 +775,23 @@ __device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, Me
     }
 }
 
-template <typename A>
-__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A> &m) {
-    constexpr int VW = 16 / sizeof(A);
+template <typename A, int NT>
+__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT> &m) {
+    constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ;
     const int tid = threadIdx.x, vc = tid & 31, grp = tid >> 5;
     const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
     const int nvc = (2 * T + VW - 1) / VW;  // 16-byte columns of W
     const char *base = reinterpret_cast<const char *>(recs);
-    const unsigned off0 = (unsigned)(grp * MERGE_MAXJ) * rbytes +
-                          (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+    const unsigned off0 = (unsigned)(grp * MAXJ) * rbytes + (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
 #pragma unroll
-    for (int j = 0; j < MERGE_MAXJ; ++j)
-        m.w[j] = *reinterpret_cast<const VecT<A> *>(base + (off0 + (unsigned)j * rbytes));
+    for (int j = 0; j < MAXJ; ++j) m.w[j] = *reinterpret_cast<const VecT<A> *>(base + (off0 + (unsigned)j * rbytes));
 }
 
 // `store(i, v)` receives w_eps[i] = W[i] / eta for i in [0, 2T); rho/eta/eta2 end up in every thread.
-template <typename A, typename Store>
-__device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta, MergeRegs<A> &m,
+template <typename A, int NT, typename Store>
+__device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta, MergeRegs<A, NT> &m,
                                               A *sh_s, A *sh_part, A &rho, A &eta, A &eta2, Store store) {
-    constexpr int VW = 16 / sizeof(A);
+    constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ, GROUPS = MergeShape<NT>::GROUPS;
     using V = VecT<A>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int vc = tid & 31, grp = tid >> 5;
@@ -813,12 +815,16 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
     }
     eta = wv::reduce<wv::OpAdd>(eta);
     eta2 = wv::reduce<wv::OpAdd>(eta2);
-    // this wave's threads use the scales of records 64 wid .. 64 wid + 63 only: a wave-local exchange
-    sh_s[tid] = wid == 0 ? sc[0] : wid == 1 ? sc[1] : wid == 2 ? sc[2] : sc[3];
+    // this wave's two groups use the scales of records r0 .. r0 + 2 MAXJ - 1 only (a run inside one of the four
+    // 64-record slots every lane holds): a wave-local exchange through 64 private LDS words, no block barrier
+    const int r0 = wid * 2 * MAXJ, slot = r0 >> 6;
+    A *my_s = sh_s + wid * 64;
+    my_s[lane] = slot == 0 ? sc[0] : slot == 1 ? sc[1] : slot == 2 ? sc[2] : sc[3];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     STAMP(26);
+    const A *sj_base = my_s + (r0 & 63) + (grp & 1) * MAXJ;
     const A inv_eta = fast_div(A(1), eta);
     const int n_tiles = (nvc + 31) / 32;
     for (int vt = 0; vt < n_tiles; ++vt) {
@@ -826,21 +832,21 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
 #pragma unroll
         for (int q = 0; q < VW; ++q) acc.v[q] = 0;
 #pragma unroll
-        for (int j = 0; j < MERGE_MAXJ; ++j) {
-            const A sj = sh_s[grp * MERGE_MAXJ + j];
+        for (int j = 0; j < MAXJ; ++j) {
+            const A sj = sj_base[j];
 #pragma unroll
             for (int q = 0; q < VW; ++q) acc.v[q] += sj * m.w[j].v[q];
         }
         if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A>(recs, T, vt + 1, m);  // T > 64 only
-        for (int e = tid; e < 32 * VW; e += MERGE_THREADS) {
+        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT>(recs, T, vt + 1, m);  // T > 64 only
+        for (int e = tid; e < 32 * VW; e += NT) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
                 A t = 0;
 #pragma unroll
-                for (int g = 0; g < MERGE_GROUPS; ++g) t += sh_part[g * 32 * VW + e];
+                for (int g = 0; g < GROUPS; ++g) t += sh_part[g * 32 * VW + e];
                 store(i, t * inv_eta);  // w_eps = W / eta, :132-135
             }
         }
@@ -886,11 +892,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     A *sh_w = L.w;
     const int b0 = blockIdx.x * group, nb = min(group, n - b0);
     const A *mine = recs + (size_t)b0 * record_len(T, (int)sizeof(A));
-    MergeRegs<A> mr;
-    merge_load_heads<A>(heads + 4 * (size_t)b0, mr);
-    merge_load_tile<A>(mine, T, 0, mr);
+    MergeRegs<A, MERGE_THREADS> mr;
+    merge_load_heads<A, MERGE_THREADS>(heads + 4 * (size_t)b0, mr);
+    merge_load_tile<A, MERGE_THREADS>(mine, T, 0, mr);
     A rho, eta, eta2;
-    merge_combine<A>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
+    merge_combine<A, MERGE_THREADS>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
     // merge_combine leaves W / eta; a record carries W itself
     if (ABI_OUT) {
         double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
@@ -952,38 +958,55 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 
 // MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
 // caller (doubles, ABI layout); 2: block records + peer-to-peer exchange of the per-rank record
-// The leading arguments repeat F.partials, F.heads, F.st, F.u and F.T: the dispatcher preloads them into SGPRs
-// (-amdgpu-kernarg-preload-count), so the first loads are issued without waiting for the kernel-argument fetch.
-template <typename A, int MODE>
-__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
-                                                            const DevState *st_pre, const void *u_pre, int T_pre,
-                                                            const FinalizeParams F) {
+// What the prologue of k_iter hands to the rollout that follows it in the same launch (LDS).
+struct IterCarry {
+    DevState st;   // the controller state the rollouts of this launch start from
+    int outcome;   // FIN_*
+    int pad;
+};
+constexpr int FIN_DONE = 0, FIN_NEED_ROUND = 1, FIN_PATH_END = 2, FIN_EXCHANGE_FAILED = 3, FIN_NOTHING_PENDING = 4;
+
+// S7 as a function of the calling workgroup: merge the records of the finished rollouts, moving average, update,
+// shift, plant, next x0 call.  NT = 256, ITER = false: the body of k_finalize (one workgroup, state and controls
+// updated where they are or into F.st_out / F.u_out).  NT = 1024, ITER = true: the prologue every workgroup of
+// k_iter runs redundantly -- the results stay in LDS (`carry`, `sh_un` = the shifted controls) for the rollout that
+// follows in the same launch, and only workgroup 0 writes them to memory.
+// The *_pre arguments repeat F.partials, F.heads, F.st, F.u and F.T: leading kernel arguments that the dispatcher
+// preloads into SGPRs (-amdgpu-kernarg-preload-count), so the first loads do not wait for the argument fetch.
+template <typename A, int MODE, int NT, bool ITER>
+__device__ __forceinline__ int finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
+                                             const void *u_pre, int T_pre, const FinalizeParams &F, char *smem,
+                                             IterCarry *carry, A *sh_un) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(MODE == 0 || NT == MERGE_THREADS, "the ABI / exchange variants are 256-thread kernels");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool wg = !ITER || blockIdx.x == 0;  // this workgroup writes the results to memory
     const int T = F.T, W = F.filter_window, H = W / 2;
-    const MergeLds<A> L(smem, T, W);
+    const MergeLds<A, NT> L(smem, T, W);
     A *sh_w = L.w;  // weighted noise in the filter's padded layout: sample t of channel d at [2 (t + H) + d]
     A *sh_u = L.u;  // [2T] updated u
-    DevState *st = F.st;
+    DevState *st_out = F.st_out;
     StepResult *res = F.res;
     double *res_u = reinterpret_cast<double *>(res + 1);
-    A *u_dev = reinterpret_cast<A *>(F.u), *u_hist = reinterpret_cast<A *>(F.u_before);
+    const A *u_in = reinterpret_cast<const A *>(u_pre);
+    A *u_out = reinterpret_cast<A *>(F.u_out), *u_hist = reinterpret_cast<A *>(F.u_before);
     const A *ref = reinterpret_cast<const A *>(F.ref);
 
     STAMP(16);
     // ---- every load that nothing below produces, issued before anything waits: this thread's u, the
-    // records (their addresses depend on nothing but the kernel arguments) and the state as ONE batch of
-    // scalar loads -- a single memory round trip covers all of them
+    // records (their addresses depend on nothing but the kernel arguments) and the state -- a single memory
+    // round trip covers all of them
     // (the state as one VECTOR load, lane i <- dword i: vector loads return in issue order, so it arrives
     // before the records queued behind it; scalar loads would be issued after them and wait for the queue)
     static_assert(sizeof(DevState) == 72, "DevState layout");
     const int st_word = reinterpret_cast<const int *>(st_pre)[lane < 18 ? lane : 0];
-    const A u_old = tid < 2 * T_pre ? reinterpret_cast<const A *>(u_pre)[tid] : A(0);  // elements >= 256: re-read below
-    MergeRegs<A> mr;
-    if (!ABI_RECS) {
-        merge_load_heads<A>(reinterpret_cast<const A *>(heads_pre), mr);
-        merge_load_tile<A>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
+    int fk_ring = NO_TRIGGER;
+    if (ITER && F.pending) fk_ring = *F.trig_in;
+    const A u_old = tid < 2 * T_pre ? u_in[tid] : A(0);  // elements >= NT: re-read below
+    MergeRegs<A, NT> mr;
+    if (!ABI_RECS && (!ITER || F.pending)) {
+        merge_load_heads<A, NT>(reinterpret_cast<const A *>(heads_pre), mr);
+        merge_load_tile<A, NT>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
     STAMP(24);
     DevState sv;
@@ -997,7 +1020,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
         sv.round = word(12); sv.path_end = word(13); sv.idx_start = word(14); sv.pad = 0;
         sv.iter = ((long long)word(17) << 32) | (unsigned int)word(16);
     }
-    const int fk = sv.first_k, round = sv.round;
+    const int fk = ITER ? fk_ring : sv.first_k, round = sv.round;
     // first round of a synchronous step: the observed state and its x0 index came as kernel arguments
     const bool args = F.use_args && round == 0;
     const int c_state = args ? F.c_arg : sv.c;
@@ -1006,43 +1029,56 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
     const long long iter = sv.iter;
     const double x0v[4] = {args ? F.x0_arg[0] : sv.x0[0], args ? F.x0_arg[1] : sv.x0[1],
                            args ? F.x0_arg[2] : sv.x0[2], args ? F.x0_arg[3] : sv.x0[3]};
+    // the state as this call found it, with the observed state folded in: what every exit starts from
+    DevState nx = sv;
+    nx.x0[0] = x0v[0]; nx.x0[1] = x0v[1]; nx.x0[2] = x0v[2]; nx.x0[3] = x0v[3];
+    nx.c = c_state; nx.p = p_state; nx.idx_start = idx_start; nx.path_end = path_end;
+    nx.first_k = NO_TRIGGER;
     auto publish = [&]() {  // completion word for a polling host: every result store first, system-wide
         __syncthreads();
-        if (tid == 0 && F.seq) {
+        if (!ITER && tid == 0 && F.seq) {
             __threadfence_system();
             *reinterpret_cast<volatile long long *>(&res->seq) = F.seq;
         }
     };
+    // an exit that leaves the controls as they are: state (+ for k_iter the unchanged controls) out
+    auto leave = [&](int outcome) {
+        if (tid == 0) {
+            if (wg) *st_out = nx;
+            if (ITER) { carry->st = nx; carry->outcome = outcome; }
+            if (ITER && wg) *F.trig_reset = NO_TRIGGER;
+        }
+        if (ITER || u_out != u_in)
+            for (int i = tid; i < 2 * T; i += NT) {
+                const A uo = i == tid ? u_old : u_in[i];
+                if (ITER) sh_un[i] = uo;
+                if (wg && u_out != u_in) u_out[i] = uo;
+            }
+        publish();
+        return outcome;
+    };
 
+    if (ITER && !F.pending) return leave(FIN_NOTHING_PENDING);  // first launch of a batch: no rollouts to finish yet
     if (XCHG && *reinterpret_cast<volatile int *>(F.x_err)) {  // an earlier exchange failed: do not wait again
         if (tid == 0) { res->status = STATUS_EXCHANGE_FAILED; res->iter = iter; }
-        publish();
-        return;
+        return leave(FIN_EXCHANGE_FAILED);
     }
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
     if (F.sequential && fk != NO_TRIGGER) {
         const int c_new = F.pout[fk];
         if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
-            if (tid == 0) {
-                st->k_start = fk + 1;
-                st->c = c_new;
-                st->first_k = NO_TRIGGER;
-                st->round = round + 1;
-                if (args) {  // the repair rounds read the state from *st
-                    st->x0[0] = x0v[0]; st->x0[1] = x0v[1]; st->x0[2] = x0v[2]; st->x0[3] = x0v[3];
-                    st->idx_start = idx_start;
-                    st->path_end = path_end;
-                    st->p = p_state;
-                }
+            nx.k_start = fk + 1;
+            nx.c = c_new;
+            nx.round = round + 1;
+            if (wg && tid == 0) {
                 res->status = STATUS_NEED_ROUND;
                 res->k_next = fk + 1;
                 res->c_next = c_new;
                 res->rounds = round + 1;
                 res->iter = iter;
             }
-            publish();
-            return;
+            return leave(FIN_NEED_ROUND);
         }
         c_final = c_new;
     }
@@ -1076,17 +1112,17 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
     } else if (!XCHG) {
-        merge_combine<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
-                         eta2, store_w);
+        merge_combine<A, NT>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
+                             eta2, store_w);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
-        merge_combine<A>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
-                         eta2, [&](int i, A v) { sh_u[i] = v; });
+        merge_combine<A, NT>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
+                             eta2, [&](int i, A v) { sh_u[i] = v; });
         const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(T, F.x_nranks);
         const size_t rec_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)F.x_rank * xchg_rec_len(T);
         for (int p = 0; p < F.x_nranks; ++p) {
             double *rec = reinterpret_cast<double *>(F.x_peers[p] + rec_off);
-            for (int i = tid; i < 2 * T; i += MERGE_THREADS) rec[3 + i] = (double)(sh_u[i] * eta);  // W itself
+            for (int i = tid; i < 2 * T; i += NT) rec[3 + i] = (double)(sh_u[i] * eta);  // W itself
             if (tid == 0) { rec[0] = (double)rho; rec[1] = (double)eta; rec[2] = (double)eta2; }
         }
         if (!exchange_flags(F, slot_off)) {  // a peer never arrived: nothing is updated
@@ -1094,17 +1130,27 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                 res->status = STATUS_EXCHANGE_FAILED;
                 res->rounds = round + 1; res->iter = iter;
             }
-            publish();
-            return;
+            return leave(FIN_EXCHANGE_FAILED);
         }
         const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
         merge_abi<A>(recs, F.x_nranks, T, (A)F.beta, L.s, L.red, rho, eta, eta2, store_w, xchg_rec_len(T));
     }
     STAMP(18);
 
+    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
+        nx.k_start = 0;
+        nx.round = 0;
+        if (wg && tid == 0) {
+            res->status = STATUS_PATH_END;
+            res->idx_start = idx_start; res->idx_after = p_state; res->path_end = 1;
+            res->rounds = round + 1; res->iter = iter;
+        }
+        return leave(FIN_PATH_END);
+    }
+
     // --- moving average of w_eps (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order ------
     const A inv_w = fast_div(A(1), (A)W);
-    for (int i = tid; i < 2 * T; i += blockDim.x) {
+    for (int i = tid; i < 2 * T; i += NT) {
         const int t = i >> 1, d = i & 1;
         A f;
         if (F.filter_mode == FILTER_NONE) {
@@ -1127,33 +1173,25 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
             }
             f = sacc;
         }
-        const A uo = i == tid ? u_old : u_dev[i];
+        const A uo = i == tid ? u_old : u_in[i];
         A un = uo + f;                                                        // u += w_epsilon, :141
         if (F.clamp_u) un = mf::clamp(un, d == 0 ? (A)F.umax0 : (A)F.umax1);  // :145-149
         sh_u[i] = un;
     }
     __syncthreads();
-    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
-        if (tid == 0) {
-            res->status = STATUS_PATH_END;
-            res->idx_start = idx_start; res->idx_after = p_state; res->path_end = 1;
-            res->rounds = round + 1; res->iter = iter;
-            st->first_k = NO_TRIGGER; st->k_start = 0; st->round = 0;
-            st->p = p_state;
-        }
-        publish();
-        return;
-    }
     STAMP(19);
     // --- shift (:162-163); the returned sequence aliases u_prev (:165) ---------------------
-    for (int i = tid; i < 2 * T; i += blockDim.x) {
+    for (int i = tid; i < 2 * T; i += NT) {
         const int t = i >> 1, d = i & 1;
-        const A uo = i == tid ? u_old : u_dev[i];
+        const A uo = i == tid ? u_old : u_in[i];
         const A shifted = sh_u[2 * (t < T - 1 ? t + 1 : T - 1) + d];
-        u_hist[i] = uo;               // u before the update and the updated, unshifted u: viz rollouts
-        u_hist[2 * T + i] = sh_u[i];
-        res_u[i] = (double)shifted;
-        u_dev[i] = shifted;  // element i is read and written by this thread only
+        if (ITER) sh_un[i] = shifted;
+        if (wg) {
+            u_hist[i] = uo;               // u before the update and the updated, unshifted u: viz rollouts
+            u_hist[2 * T + i] = sh_u[i];
+            res_u[i] = (double)shifted;
+            u_out[i] = shifted;  // element i is read and written by this thread only
+        }
     }
 
     STAMP(20);
@@ -1174,7 +1212,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                 xn[3] += (double)accel * F.dt;
             }
         }
-        if (lane == 0) {
+        nx.iter = iter + 1;
+        nx.k_start = 0;
+        nx.round = 0;
+        nx.p = p_now;
+        if (wg && lane == 0) {
             res->status = STATUS_DONE;
             res->k_next = 0; res->c_next = c_final;
             res->idx_start = idx_start;
@@ -1186,17 +1228,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];
             if (F.u0_trace) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
             res->iter = iter + 1;
-            st->iter = iter + 1;
-            st->first_k = NO_TRIGGER;
-            st->k_start = 0;
-            st->round = 0;
-            st->p = p_now;
-            if (args) {  // keep *st the single source of truth for every other entry point
-                st->x0[0] = x0v[0]; st->x0[1] = x0v[1]; st->x0[2] = x0v[2]; st->x0[3] = x0v[3];
-                st->c = c_state;
-                st->idx_start = idx_start;
-                st->path_end = path_end;
-            }
         }
         if (F.plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
             A best = A(INFINITY);
@@ -1213,18 +1244,31 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                 if (dd < best) { best = dd; bj = j; }
             }
             wv::argmin_first(best, bj);
-            if (lane == 0) {
-                const int c = p_now + bj;
-                st->x0[0] = xn[0]; st->x0[1] = xn[1]; st->x0[2] = xn[2]; st->x0[3] = xn[3];
-                st->c = c;
-                st->idx_start = c;
-                st->path_end = c >= F.n_ref - 1;
-                if (!F.sequential) st->p = c;
-            }
+            const int c = p_now + bj;
+            nx.x0[0] = xn[0]; nx.x0[1] = xn[1]; nx.x0[2] = xn[2]; nx.x0[3] = xn[3];
+            nx.c = c;
+            nx.idx_start = c;
+            nx.path_end = c >= F.n_ref - 1;
+            if (!F.sequential) nx.p = c;
+        }
+        if (lane == 0) {
+            if (wg) *st_out = nx;
+            if (ITER) { carry->st = nx; carry->outcome = FIN_DONE; }
+            if (ITER && wg) *F.trig_reset = NO_TRIGGER;
         }
     }
     publish();
     STAMP(21);
+    return FIN_DONE;
+}
+
+template <typename A, int MODE>
+__global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
+                                                            const DevState *st_pre, const void *u_pre, int T_pre,
+                                                            const FinalizeParams F) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    finalize_body<A, MODE, MERGE_THREADS, false>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, nullptr,
+                                                 (A *)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
