@@ -90,10 +90,6 @@ struct FinalizeParams {
     void *u;                 // [T][2] in the kernel precision: the controls the finished rollouts used
     void *u_out;             // where the updated, shifted controls go (== u: in place)
     DevState *st_out;        // where the state after this call goes (== st: in place)
-    // one launch per iteration (k_iter): this call finishes the rollouts of the PREVIOUS launch
-    int pending, pad3;       // 0: nothing to finish yet (first launch of a batch)
-    const int *trig_in;      // first_k the previous launch's rollouts left (ring of three, see k_iter)
-    int *trig_reset;         // the ring slot the NEXT launch's rollouts will use: reset here
     void *u_before;          // copy of u before the update (for the viz rollouts)
     const void *ref;         // [n_ref][4] kernel precision
     const int *pout;

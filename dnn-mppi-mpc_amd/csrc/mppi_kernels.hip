@@ -958,29 +958,16 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 
 // MODE 0: F.partials = this GPU's block records (handle precision); 1: = the ranks' records, gathered by the
 // caller (doubles, ABI layout); 2: block records + peer-to-peer exchange of the per-rank record
-// What the prologue of k_iter hands to the rollout that follows it in the same launch (LDS).
-struct IterCarry {
-    DevState st;   // the controller state the rollouts of this launch start from
-    int outcome;   // FIN_*
-    int pad;
-};
-constexpr int FIN_DONE = 0, FIN_NEED_ROUND = 1, FIN_PATH_END = 2, FIN_EXCHANGE_FAILED = 3, FIN_NOTHING_PENDING = 4;
-
-// S7 as a function of the calling workgroup: merge the records of the finished rollouts, moving average, update,
-// shift, plant, next x0 call.  NT = 256, ITER = false: the body of k_finalize (one workgroup, state and controls
-// updated where they are or into F.st_out / F.u_out).  NT = 1024, ITER = true: the prologue every workgroup of
-// k_iter runs redundantly -- the results stay in LDS (`carry`, `sh_un` = the shifted controls) for the rollout that
-// follows in the same launch, and only workgroup 0 writes them to memory.
+// S7: merge the records of the finished rollouts, moving average, update, shift, plant, next x0 call -- one
+// workgroup of NT threads; state and controls are updated where they are or into F.st_out / F.u_out.
 // The *_pre arguments repeat F.partials, F.heads, F.st, F.u and F.T: leading kernel arguments that the dispatcher
 // preloads into SGPRs (-amdgpu-kernarg-preload-count), so the first loads do not wait for the argument fetch.
-template <typename A, int MODE, int NT, bool ITER>
-__device__ __forceinline__ int finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
-                                             const void *u_pre, int T_pre, const FinalizeParams &F, char *smem,
-                                             IterCarry *carry, A *sh_un) {
+template <typename A, int MODE, int NT>
+__device__ __forceinline__ void finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
+                                              const void *u_pre, int T_pre, const FinalizeParams &F, char *smem) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
     static_assert(MODE == 0 || NT == MERGE_THREADS, "the ABI / exchange variants are 256-thread kernels");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool wg = !ITER || blockIdx.x == 0;  // this workgroup writes the results to memory
     const int T = F.T, W = F.filter_window, H = W / 2;
     const MergeLds<A, NT> L(smem, T, W);
     A *sh_w = L.w;  // weighted noise in the filter's padded layout: sample t of channel d at [2 (t + H) + d]
@@ -1000,11 +987,9 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
     // before the records queued behind it; scalar loads would be issued after them and wait for the queue)
     static_assert(sizeof(DevState) == 72, "DevState layout");
     const int st_word = reinterpret_cast<const int *>(st_pre)[lane < 18 ? lane : 0];
-    int fk_ring = NO_TRIGGER;
-    if (ITER && F.pending) fk_ring = *F.trig_in;
     const A u_old = tid < 2 * T_pre ? u_in[tid] : A(0);  // elements >= NT: re-read below
     MergeRegs<A, NT> mr;
-    if (!ABI_RECS && (!ITER || F.pending)) {
+    if (!ABI_RECS) {
         merge_load_heads<A, NT>(reinterpret_cast<const A *>(heads_pre), mr);
         merge_load_tile<A, NT>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
@@ -1020,7 +1005,7 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
         sv.round = word(12); sv.path_end = word(13); sv.idx_start = word(14); sv.pad = 0;
         sv.iter = ((long long)word(17) << 32) | (unsigned int)word(16);
     }
-    const int fk = ITER ? fk_ring : sv.first_k, round = sv.round;
+    const int fk = sv.first_k, round = sv.round;
     // first round of a synchronous step: the observed state and its x0 index came as kernel arguments
     const bool args = F.use_args && round == 0;
     const int c_state = args ? F.c_arg : sv.c;
@@ -1036,32 +1021,22 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
     nx.first_k = NO_TRIGGER;
     auto publish = [&]() {  // completion word for a polling host: every result store first, system-wide
         __syncthreads();
-        if (!ITER && tid == 0 && F.seq) {
+        if (tid == 0 && F.seq) {
             __threadfence_system();
             *reinterpret_cast<volatile long long *>(&res->seq) = F.seq;
         }
     };
-    // an exit that leaves the controls as they are: state (+ for k_iter the unchanged controls) out
-    auto leave = [&](int outcome) {
-        if (tid == 0) {
-            if (wg) *st_out = nx;
-            if (ITER) { carry->st = nx; carry->outcome = outcome; }
-            if (ITER && wg) *F.trig_reset = NO_TRIGGER;
-        }
-        if (ITER || u_out != u_in)
-            for (int i = tid; i < 2 * T; i += NT) {
-                const A uo = i == tid ? u_old : u_in[i];
-                if (ITER) sh_un[i] = uo;
-                if (wg && u_out != u_in) u_out[i] = uo;
-            }
+    // an exit that leaves the controls as they are: the state (and, when they go elsewhere, the controls) out
+    auto leave = [&]() {
+        if (tid == 0) *st_out = nx;
+        if (u_out != u_in)
+            for (int i = tid; i < 2 * T; i += NT) u_out[i] = i == tid ? u_old : u_in[i];
         publish();
-        return outcome;
     };
 
-    if (ITER && !F.pending) return leave(FIN_NOTHING_PENDING);  // first launch of a batch: no rollouts to finish yet
     if (XCHG && *reinterpret_cast<volatile int *>(F.x_err)) {  // an earlier exchange failed: do not wait again
         if (tid == 0) { res->status = STATUS_EXCHANGE_FAILED; res->iter = iter; }
-        return leave(FIN_EXCHANGE_FAILED);
+        return leave();
     }
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
@@ -1071,14 +1046,14 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
             nx.k_start = fk + 1;
             nx.c = c_new;
             nx.round = round + 1;
-            if (wg && tid == 0) {
+            if (tid == 0) {
                 res->status = STATUS_NEED_ROUND;
                 res->k_next = fk + 1;
                 res->c_next = c_new;
                 res->rounds = round + 1;
                 res->iter = iter;
             }
-            return leave(FIN_NEED_ROUND);
+            return leave();
         }
         c_final = c_new;
     }
@@ -1130,7 +1105,7 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
                 res->status = STATUS_EXCHANGE_FAILED;
                 res->rounds = round + 1; res->iter = iter;
             }
-            return leave(FIN_EXCHANGE_FAILED);
+            return leave();
         }
         const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
         merge_abi<A>(recs, F.x_nranks, T, (A)F.beta, L.s, L.red, rho, eta, eta2, store_w, xchg_rec_len(T));
@@ -1140,12 +1115,12 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
     if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
         nx.k_start = 0;
         nx.round = 0;
-        if (wg && tid == 0) {
+        if (tid == 0) {
             res->status = STATUS_PATH_END;
             res->idx_start = idx_start; res->idx_after = p_state; res->path_end = 1;
             res->rounds = round + 1; res->iter = iter;
         }
-        return leave(FIN_PATH_END);
+        return leave();
     }
 
     // --- moving average of w_eps (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order ------
@@ -1185,13 +1160,10 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
         const int t = i >> 1, d = i & 1;
         const A uo = i == tid ? u_old : u_in[i];
         const A shifted = sh_u[2 * (t < T - 1 ? t + 1 : T - 1) + d];
-        if (ITER) sh_un[i] = shifted;
-        if (wg) {
-            u_hist[i] = uo;               // u before the update and the updated, unshifted u: viz rollouts
-            u_hist[2 * T + i] = sh_u[i];
-            res_u[i] = (double)shifted;
-            u_out[i] = shifted;  // element i is read and written by this thread only
-        }
+        u_hist[i] = uo;               // u before the update and the updated, unshifted u: viz rollouts
+        u_hist[2 * T + i] = sh_u[i];
+        res_u[i] = (double)shifted;
+        u_out[i] = shifted;  // element i is read and written by this thread only
     }
 
     STAMP(20);
@@ -1216,7 +1188,7 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
         nx.k_start = 0;
         nx.round = 0;
         nx.p = p_now;
-        if (wg && lane == 0) {
+        if (lane == 0) {
             res->status = STATUS_DONE;
             res->k_next = 0; res->c_next = c_final;
             res->idx_start = idx_start;
@@ -1251,15 +1223,10 @@ __device__ __forceinline__ int finalize_body(const void *partials_pre, const voi
             nx.path_end = c >= F.n_ref - 1;
             if (!F.sequential) nx.p = c;
         }
-        if (lane == 0) {
-            if (wg) *st_out = nx;
-            if (ITER) { carry->st = nx; carry->outcome = FIN_DONE; }
-            if (ITER && wg) *F.trig_reset = NO_TRIGGER;
-        }
+        if (lane == 0) *st_out = nx;
     }
     publish();
     STAMP(21);
-    return FIN_DONE;
 }
 
 template <typename A, int MODE>
@@ -1267,8 +1234,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                                                             const DevState *st_pre, const void *u_pre, int T_pre,
                                                             const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    finalize_body<A, MODE, MERGE_THREADS, false>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, nullptr,
-                                                 (A *)nullptr);
+    finalize_body<A, MODE, MERGE_THREADS>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem);
 }
 
 // ------------------------------------------------------------------------------------------
