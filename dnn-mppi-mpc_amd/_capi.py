@@ -16,7 +16,7 @@ MODEL_DIFFDRIVE, MODEL_RACECAR, MODEL_DIFFDRIVE_MLP = 0, 1, 2
 PREC_F32, PREC_F64 = 0, 1
 WAYPOINT_SEQUENTIAL, WAYPOINT_FROZEN = 0, 1
 BETA_INV_EXPLORATION, BETA_INV_LAMBDA, BETA_LAMBDA = 0, 1, 2
-FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE = 0, 1, 2
+FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE, FILTER_TORCH = 0, 1, 2, 3
 OBSTACLE_NONE, OBSTACLE_CIRCLE, OBSTACLE_OUTLINE = 0, 1, 2
 OK, ERR_BAD_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_PATH_END, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 ERR_COMM = -8

@@ -357,7 +357,7 @@ class MPPIAlgorithms(_ControllerBase):
             wrap_yaw_stage=0, wrap_yaw_terminal=0 if variant == "numpy" else 1,
             clamp_rollout=0 if variant == "torch" else 1,
             clamp_u_after_update=int(self.visualze_sampled_trajs),  # :145-149
-            filter_mode=capi.FILTER_RACECAR if variant == "torch" else capi.FILTER_DIFFDRIVE,
+            filter_mode=capi.FILTER_TORCH if variant == "torch" else capi.FILTER_DIFFDRIVE,  # _torch.py:252-263
             obstacle_model=capi.OBSTACLE_CIRCLE if obstacle_circles is not None else capi.OBSTACLE_NONE,
             raise_at_path_end=0,
             safety_margin=0.0 if safety_margin_rate is None else self.safefy_margin_rate,
@@ -401,7 +401,12 @@ class MPPIRacecarController(_ControllerBase):
                  param_exploration=0.01, param_lambda=50.0, param_alpha=1.0, sigma=((0.5, 0.0), (0.0, 0.1)),
                  stage_cost_weight=(50.0, 50.0, 1.0, 20.0), terminal_cost_weight=(50.0, 50.0, 1.0, 20.0),
                  obstacle_circles=None, collision_safety_margin_rat=1.5, visualize_optimal_traj=True,
-                 visualze_sampled_trajs=True, *, precision="f32", device=0, seed=0, process_group=None):
+                 visualze_sampled_trajs=True, *, variant="numpy", precision="f32", device=0, seed=0, process_group=None):
+        if variant not in ("numpy", "cupy", "torch"):
+            raise ValueError("variant must be 'numpy', 'cupy' or 'torch'")
+        # mppi_race_car_cupy.py is the NumPy file with cp. for np.; mppi_race_car_torch.py differs in its moving
+        # average (conv1d over the padded signal, first T outputs: the NumPy filter delayed by window/2 rows)
+        self.variant = variant
         self.dim_x, self.dim_u = 4, 2
         self.T = _int(horizon_step_T)
         self.K = _int(number_of_samples_K)
@@ -433,7 +438,7 @@ class MPPIRacecarController(_ControllerBase):
             waypoint_mode=capi.WAYPOINT_FROZEN, search_window=200,  # :143,:158
             wrap_yaw_stage=1, wrap_yaw_terminal=1,  # :141,:150
             clamp_rollout=1, clamp_u_after_update=int(self.visualize_optimal_traj),  # :102-106
-            filter_mode=capi.FILTER_RACECAR,
+            filter_mode=capi.FILTER_TORCH if variant == "torch" else capi.FILTER_RACECAR,  # _torch.py:211-222
             obstacle_model=capi.OBSTACLE_OUTLINE if self._has_obstacles else capi.OBSTACLE_NONE,
             raise_at_path_end=0 if self._has_obstacles else 1,  # mppi_race_car.py:63-65 vs _obstacle.py:73-74
             safety_margin=self.collision_safety_margin_rate, vehicle_w=self.vehicle_w, vehicle_l=self.vehicle_l,

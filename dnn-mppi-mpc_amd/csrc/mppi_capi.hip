@@ -132,7 +132,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (c.filter_mode == MPPI_FILTER_DIFFDRIVE && c.T < c.filter_window)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "horizon T=%d is shorter than the moving-average window %d", c.T,
              c.filter_window);
-    if (c.filter_mode == MPPI_FILTER_RACECAR && c.T < c.filter_window / 2)
+    if ((c.filter_mode == MPPI_FILTER_RACECAR || c.filter_mode == MPPI_FILTER_TORCH) && c.T < c.filter_window / 2)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "horizon T=%d is shorter than half the filter window %d", c.T,
              c.filter_window);
     if (c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && c.K_global != c.K)

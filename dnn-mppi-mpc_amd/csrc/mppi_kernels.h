@@ -7,7 +7,7 @@ namespace mppi {
 
 constexpr int MODEL_DIFF = 0, MODEL_RACE = 1;
 constexpr int OBS_NONE = 0, OBS_CIRCLE = 1, OBS_OUTLINE = 2;
-constexpr int FILTER_DIFF = 0, FILTER_RACE = 1, FILTER_NONE = 2;
+constexpr int FILTER_DIFF = 0, FILTER_RACE = 1, FILTER_NONE = 2, FILTER_TORCH = 3;
 constexpr int NO_TRIGGER = 0x7fffffff;
 constexpr int STATUS_DONE = 0, STATUS_NEED_ROUND = 1, STATUS_PATH_END = 2, STATUS_EXCHANGE_FAILED = 3;
 

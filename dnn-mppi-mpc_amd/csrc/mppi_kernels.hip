@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     // w_eps lands in the padded layout the filter reads: H leading and W - H trailing slots hold zeros
     // (np.convolve 'same', mppi_differential_drive.py:257-263) or copies of the first / last H samples
     // (mppi_race_car.py:211-222: the padded signal is xx[:H] + xx + xx[-H:])
-    const bool pad_copy = F.filter_mode == FILTER_RACE;
+    const bool pad_copy = F.filter_mode == FILTER_RACE || F.filter_mode == FILTER_TORCH;
     auto store_w = [&](int i, A v) {
         const int t = i >> 1, d = i & 1;
         const A pv = pad_copy ? v : A(0);
@@ -1130,6 +1130,15 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         A f;
         if (F.filter_mode == FILTER_NONE) {
             f = sh_w[2 * (t + H) + d];
+        } else if (F.filter_mode == FILTER_TORCH) {
+            // conv1d(padding = H) over the padded signal, first T outputs (mppi_race_car_torch.py:211-222):
+            // output t = padded rows t-H .. t-H+W-1, rows before the start are the convolution's zero padding
+            A sacc = 0;
+            for (int q = 0; q < W; ++q) {
+                const int m = t - H + q;
+                if (m >= 0) sacc += sh_w[2 * m + d] * inv_w;
+            }
+            f = sacc;
         } else {
             const A *tap = sh_w + 2 * t + d;
             A sacc = 0;

@@ -63,8 +63,13 @@ typedef enum { MPPI_BETA_INV_EXPLORATION = 0, MPPI_BETA_INV_LAMBDA = 1, MPPI_BET
 /* smoothing of the weighted noise:
  *  DIFFDRIVE  np.convolve 'same' + edge factors incl. the repeated last-row factor
  *             (mppi_differential_drive.py:257-271)
- *  RACECAR    pad with first/last window/2 rows, convolve, unpad (mppi_race_car.py:211-222) */
-typedef enum { MPPI_FILTER_DIFFDRIVE = 0, MPPI_FILTER_RACECAR = 1, MPPI_FILTER_NONE = 2 } mppi_filter_mode;
+ *  RACECAR    pad with first/last window/2 rows, convolve, unpad (mppi_race_car.py:211-222)
+ *  TORCH      the torch files' variant of RACECAR: same padding, `conv1d(padding=window/2)` and the FIRST T
+ *             outputs, i.e. output n averages padded rows n-5 .. n+4 with zeros before the start
+ *             (mppi_differential_drive_torch.py:252-263, mppi_race_car_torch.py:211-222) */
+typedef enum {
+    MPPI_FILTER_DIFFDRIVE = 0, MPPI_FILTER_RACECAR = 1, MPPI_FILTER_NONE = 2, MPPI_FILTER_TORCH = 3
+} mppi_filter_mode;
 /* collision term (adds collision_penalty per colliding stage/terminal state):
  *  CIRCLE   robot disc of radius 0.5*margin vs circles (mppi_differential_drive_obs.py:301-313)
  *  OUTLINE  9 outline points of the (l*m) x (w*m) box vs circles (mppi_race_car_obstacle.py:241-274) */

@@ -287,3 +287,29 @@ def gen_paths():
 
 if __name__ == "__main__" and "paths" in (sys.argv[1:] or ["paths"]):
     gen_paths()
+
+
+def gen_filters():
+    """The three `_moving_average_filter` implementations of the reference, called directly on seeded inputs:
+    NumPy diff-drive (mppi_differential_drive.py:257-271), NumPy race car (mppi_race_car.py:211-222) and the
+    torch one (mppi_differential_drive_torch.py:252-263 == mppi_race_car_torch.py:211-222, on the CPU)."""
+    import torch
+    from controllers.mppi_differential_drive import MPPIAlgorithms as DD
+    from controllers.mppi_race_car import MPPIRacecarController as RC
+    from controllers.mppi_differential_drive_torch import MPPIAlgorithms as DDT
+    from controllers.mppi_race_car_torch import MPPIRacecarController as RCT
+    rng = np.random.default_rng(20240807)
+    arrays = {}
+    for T in (10, 13, 20, 50, 75):
+        xx = rng.normal(size=(T, 2)) * np.array([0.3, 0.05])
+        arrays[f"in_T{T}"] = xx
+        arrays[f"dd_T{T}"] = DD._moving_average_filter(None, xx=xx.copy(), window_size=10)
+        arrays[f"rc_T{T}"] = RC._moving_average_filter(None, xx.astype(np.float32), window_size=10)
+        xt = torch.from_numpy(xx.astype(np.float32))
+        arrays[f"ddtorch_T{T}"] = DDT._moving_average_filter(None, xt.clone(), 10).numpy()
+        arrays[f"rctorch_T{T}"] = RCT._moving_average_filter(None, xt.clone(), 10).numpy()
+    save("filters", {"window_size": 10, "torch": torch.__version__}, arrays)
+
+
+if __name__ == "__main__" and "filters" in sys.argv[1:]:
+    gen_filters()

@@ -59,6 +59,25 @@ def moving_average_diffdrive(xx: np.ndarray, window_size: int = 10) -> np.ndarra
     return xx_mean
 
 
+def moving_average_torch(xx: np.ndarray, window_size: int = 10) -> np.ndarray:
+    """mppi_differential_drive_torch.py:252-263 == mppi_race_car_torch.py:211-222: the signal padded with copies of
+    its first / last window//2 rows goes through ``conv1d(padding=window//2)`` and the FIRST T outputs are kept --
+    so output n averages padded rows n-5 .. n+4 with zeros before the start, i.e. the NumPy race-car filter delayed
+    by window//2 rows (pinned by tests/golden/filters.npz; f32 like the torch files)."""
+    h = window_size // 2
+    xx = np.asarray(xx, np.float32)
+    T = xx.shape[0]
+    padded = np.concatenate([np.zeros((h, xx.shape[1]), np.float32), xx[:h], xx, xx[T - h:]], axis=0)
+    out = np.zeros_like(xx)
+    w = np.float32(1.0 / window_size)
+    for n in range(T):
+        acc = np.zeros(xx.shape[1], np.float32)
+        for k in range(window_size):
+            acc = acc + padded[n + k] * w
+        out[n] = acc
+    return out
+
+
 def moving_average_racecar(xx: np.ndarray, window_size: int = 10) -> np.ndarray:
     """mppi_race_car.py:211-222 -- pad with copies of the first/last 5 rows, 'same'
     convolution, slice the padding off.  dtype follows ``xx`` (f32 in the reference)."""
@@ -113,6 +132,10 @@ class DiffDriveOracle:
     """Restates ``MPPIAlgorithms`` (mppi_differential_drive.py:42-289; `_obs` :42-313)."""
 
     SEARCH_IDX_LEN = 20  # mppi_differential_drive.py:204
+    # mppi_differential_drive_cuda.py is this file with np. -> cp., SEARCH_IDX_LEN = 10 (:201) and the terminal yaw
+    # wrapped into [0, 2 pi) (:239) -- set both on an instance to restate it (SURVEY.md App. B: confirmed by diffing
+    # the two sources; the file itself cannot run here, cupy is absent)
+    WRAP_YAW_TERMINAL = False
 
     def __init__(self, delta_t, ref_path, max_speed, max_omega, num_samples_K, num_horizons_T,
                  param_exploration, param_lambda, param_alpha, sigma, stage_cost_weight,
@@ -220,8 +243,9 @@ class DiffDriveOracle:
         coll = self.collided(xT, yT)
         stage = (w[0] * (xT - R[i_stage, 0]) ** 2 + w[1] * (yT - R[i_stage, 1]) ** 2
                  + w[2] * (yawT - R[i_stage, 2]) ** 2)
+        yaw_term = (yawT + 2.0 * np.pi) % (2.0 * np.pi) if self.WRAP_YAW_TERMINAL else yawT
         term = (wt[0] * (xT - R[i_term, 0]) ** 2 + wt[1] * (yT - R[i_term, 1]) ** 2
-                + wt[2] * (yawT - R[i_term, 2]) ** 2)
+                + wt[2] * (yaw_term - R[i_term, 2]) ** 2)
         if self.obstacle_circles is not None:
             stage = stage + coll * 1.0e10
             term = term + coll * 1.0e10
@@ -273,6 +297,7 @@ class RaceCarOracle:
     """Restates ``MPPIRacecarController`` (mppi_race_car.py:9-222; `_obstacle` :10-274)."""
 
     SEARCH_INDEX_LEN = 200  # mppi_race_car.py:158
+    filter_fn = staticmethod(lambda xx, w: moving_average_racecar(xx, w))  # the torch file: moving_average_torch
 
     def __init__(self, delta_t=0.05, wheel_base=2.5, max_steer_abs=0.523, max_accel_abs=2.0,
                  ref_path=None, horizon_step_T=10, number_of_samples_K=100, param_exploration=0.01,
@@ -408,7 +433,7 @@ class RaceCarOracle:
         out["w"] = w
         w_eps = sequential_sum((w[:, None, None] * eps).astype(F32), axis=0)
         out["w_eps_raw"] = w_eps
-        w_eps = moving_average_racecar(w_eps, 10)
+        w_eps = self.filter_fn(w_eps, 10)
         out["w_eps_filtered"] = w_eps
         u = (u + w_eps).astype(F32)
         out["u_pre_clamp"] = u.copy()

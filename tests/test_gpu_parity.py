@@ -158,3 +158,44 @@ def test_short_horizon_raises_like_reference():
     fx = gu.load("dd_small_T10")
     with pytest.raises(ValueError):
         make_dd(fx, "f32", num_horizons_T=9)
+
+
+@pytest.mark.parametrize("name", ["rc_circle", "rc_obs_default", "rc_obs_T75"])
+def test_racecar_torch_variant_filter(name):
+    """`variant="torch"` (mppi_race_car_torch.py): everything as in the NumPy file except the moving average, which is
+    the conv1d form pinned by tests/golden/filters.npz.  Expected = the oracle (which reproduces the fixture of the
+    NumPy file) with that one function swapped."""
+    from oracle import mppi_oracle
+    fx = gu.load(name)
+    o = gu.make_racecar_oracle(fx)
+    o.filter_fn = mppi_oracle.moving_average_torch
+    ref = o.iteration(fx["x0"], fx["eps"])
+    c = make_rc(fx, "f32", variant="torch")
+    inject(c, fx["eps"])
+    u0, u, _, _ = c._calc_control_input(fx["x0"])
+    np.testing.assert_allclose(c.sample_costs(), fx["S"], rtol=2e-5, atol=1e-3)  # the filter does not touch S
+    assert rmse(u, ref["u_returned"]) <= RMSE_TOL
+    assert rmse(u0, ref["u0_returned"]) <= RMSE_TOL
+    plain = make_rc(fx, "f32")
+    inject(plain, fx["eps"])
+    assert rmse(plain._calc_control_input(fx["x0"])[1], u) > 1e-3 or name == "rc_obs_T75"  # the variants do differ
+
+
+@pytest.mark.parametrize("name", ["dd_c1_moderate", "dd_nonzero_u", "dd_clamped"])
+def test_diffdrive_cuda_variant(name):
+    """`variant="cuda"` (mppi_differential_drive_cuda.py = the CPU file with cp. for np., a 10-waypoint search window
+    and the terminal yaw wrapped): the oracle with those two switches set.  That file cannot run here (no cupy), so
+    this pins the engine to the restatement of a source diff, not to an execution of it."""
+    fx = gu.load(name)
+    o = gu.make_diffdrive_oracle(fx)
+    o.SEARCH_IDX_LEN, o.WRAP_YAW_TERMINAL = 10, True
+    x0 = fx["x0"] + np.array([0.0, 0.0, -0.9])  # a negative yaw, so that the wrap matters
+    ref = o.iteration(x0, gu.eps_of(fx))
+    c = make_dd(fx, "f64", variant="cuda")
+    inject(c, gu.eps_of(fx))
+    u0, u, _, _ = c._calc_input_control(x0)
+    np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-7, atol=1e-9)
+    assert c.prev_way_point_idx == ref["idx_after"]
+    plain = gu.make_diffdrive_oracle(fx).iteration(x0, gu.eps_of(fx))
+    assert not np.allclose(plain["S"], ref["S"])  # the switches do change the costs

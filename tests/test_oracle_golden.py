@@ -89,3 +89,19 @@ def test_philox_sampler_moments():
     # shard invariance: rows depend on the global sample index only
     part = philox.sample_epsilon(sigma, 7, 3, 100, 50, k_offset=1000)
     np.testing.assert_array_equal(part, philox.sample_epsilon(sigma, 7, 3, 4096, 50)[1000:1100])
+
+
+@pytest.mark.parametrize("T", [10, 13, 20, 50, 75])
+def test_moving_average_filters_match_reference(T):
+    """The three `_moving_average_filter` implementations of the reference, called directly by
+    oracle/gen_golden.py (tests/golden/filters.npz): NumPy diff-drive, NumPy race car, and the torch files' conv1d
+    form (identical in mppi_differential_drive_torch.py and mppi_race_car_torch.py)."""
+    fx = gu.load("filters")
+    xx = fx[f"in_T{T}"]
+    np.testing.assert_allclose(mppi_oracle.moving_average_diffdrive(xx, 10), fx[f"dd_T{T}"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(mppi_oracle.moving_average_racecar(xx.astype(np.float32), 10), fx[f"rc_T{T}"],
+                               rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(fx[f"ddtorch_T{T}"], fx[f"rctorch_T{T}"])
+    np.testing.assert_allclose(mppi_oracle.moving_average_torch(xx, 10), fx[f"rctorch_T{T}"], rtol=1e-5, atol=1e-7)
+    # what the torch form is: the NumPy race-car filter delayed by window // 2 rows
+    np.testing.assert_allclose(fx[f"rctorch_T{T}"][5:], fx[f"rc_T{T}"][:T - 5], rtol=1e-4, atol=1e-6)
