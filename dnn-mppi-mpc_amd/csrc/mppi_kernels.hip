@@ -364,20 +364,25 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 // workgroup leaves one record per 32 samples (half as many for k_finalize to merge).  Same arithmetic per
 // step as Rollout::chunk; only the association of the prefix sums differs.
 // ------------------------------------------------------------------------------------------
+// SPW = samples per wave.  2: the layout above (T <= 64).  1: one sample per wave with two steps per lane, T <= 128 --
+// for 64 < T <= 128 this replaces two 64-step chunks of k_rollout_fused (the second one mostly idle lanes: T = 75 runs
+// 11 of 64) by one pass, ~40 % fewer instructions per sample.
 constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 
-template <typename R, int MODEL>
+template <typename R, int MODEL, int SPW>
 __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
-    __shared__ R sh_S[DUAL_SAMPLES];
-    __shared__ R sh_e[DUAL_SAMPLES];
-    __shared__ __attribute__((aligned(16))) R sh_acc[DUAL_SAMPLES][128];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+    constexpr int HL = 64 / SPW, SAMPLES = DUAL_WAVES * SPW;  // lanes per sample, samples per workgroup
+    __shared__ R sh_S[SAMPLES];
+    __shared__ R sh_e[SAMPLES];
+    __shared__ __attribute__((aligned(16))) R sh_acc[SAMPLES][4 * HL];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = SPW == 2 ? lane >> 5 : 0, l32 = lane & (HL - 1);
+    const int seg0 = h * HL;  // first lane of this lane's sample
     STAMP(0);
     const DevState sv = load_state(P, st_pre);
     const int k_start = sv.k_start;  // (no early exit for all-final workgroups, see k_rollout_fused)
     STAMP(1);
-    const int k = (blockIdx.x * DUAL_WAVES + wid) * 2 + h;    // this half's sample
+    const int k = (blockIdx.x * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
     const bool valid = k < P.K, live = valid && k >= k_start;
     const int c = sv.c;
     const unsigned iter = (unsigned)sv.iter;
@@ -435,26 +440,26 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         R px0, py0, yw0, vl0 = 0, px1, py1, yw1, vl1 = 0;  // state after the lane's first / second step
         if (MODEL == MODEL_DIFF) {  // :194-196
             const R d0 = v01 * P.dt, d1 = v11 * P.dt;
-            const R yb0 = yaw_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(d0 + d1), R(0));
+            const R yb0 = yaw_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(d0 + d1), R(0));
             yw0 = yb0 + d0;
             yw1 = yw0 + d1;
             R s0, c0, s1, c1;
             mf::sincos_(yb0, s0, c0);
             mf::sincos_(yw0, s1, c1);
             const R dx0 = v00 * c0 * P.dt, dx1 = v10 * c1 * P.dt, dy0 = v00 * s0 * P.dt, dy1 = v10 * s1 * P.dt;
-            px0 = x_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dx0 + dx1), R(0)) + dx0;
+            px0 = x_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dx0 + dx1), R(0)) + dx0;
             px1 = px0 + dx1;
-            py0 = y_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dy0 + dy1), R(0)) + dy0;
+            py0 = y_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dy0 + dy1), R(0)) + dy0;
             py1 = py0 + dy1;
         } else {  // mppi_race_car.py:190-193, controls = [steer, accel]
             const R vel_0 = (R)sv.x0[3];
             const R dv0 = a0 ? v01 * P.dt : R(0), dv1 = a1 ? v11 * P.dt : R(0);
-            const R vb0 = vel_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dv0 + dv1), R(0));
+            const R vb0 = vel_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dv0 + dv1), R(0));
             vl0 = vb0 + dv0;
             vl1 = vl0 + dv1;
             const R dp0 = a0 ? vb0 / P.wheel_base * mf::tan_(v00) * P.dt : R(0);
             const R dp1 = a1 ? vl0 / P.wheel_base * mf::tan_(v10) * P.dt : R(0);
-            const R yb0 = yaw_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dp0 + dp1), R(0));
+            const R yb0 = yaw_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dp0 + dp1), R(0));
             yw0 = yb0 + dp0;
             yw1 = yw0 + dp1;
             R s0, c0, s1, c1;
@@ -462,9 +467,9 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             mf::sincos_(yw0, s1, c1);
             const R dx0 = a0 ? vb0 * c0 * P.dt : R(0), dx1 = a1 ? vl0 * c1 * P.dt : R(0);
             const R dy0 = a0 ? vb0 * s0 * P.dt : R(0), dy1 = a1 ? vl0 * s1 * P.dt : R(0);
-            px0 = x_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dx0 + dx1), R(0)) + dx0;
+            px0 = x_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dx0 + dx1), R(0)) + dx0;
             px1 = px0 + dx1;
-            py0 = y_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dy0 + dy1), R(0)) + dy0;
+            py0 = y_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dy0 + dy1), R(0)) + dy0;
             py1 = py0 + dy1;
         }
         STAMP(10);
@@ -486,11 +491,11 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
                 trig |= (a0 && dist2(ref, c + j, px0, py0) < d00) || (a1 && dist2(ref, c + j, px1, py1) < d01);
             const unsigned long long m = __ballot(trig);
             int p_a = c, p_b = c, term_a = c, term_b = c;
-            for (int hh = 0; hh < 2; ++hh) {  // rare: thread the index through that sample's calls in order
-                if (((hh ? (m >> 32) : m) & 0xffffffffull) == 0ull) continue;
+            for (int hh = 0; hh < SPW; ++hh) {  // rare: thread the index through that sample's calls in order
+                if ((SPW == 2 ? ((hh ? (m >> 32) : m) & 0xffffffffull) : m) == 0ull) continue;
                 int p = c;
                 for (int t = 0; t < T; ++t) {
-                    const int src = hh * 32 + (t >> 1);
+                    const int src = hh * HL + (t >> 1);
                     const R xt = (t & 1) ? wv::read_lane(px1, src) : wv::read_lane(px0, src);
                     const R yt = (t & 1) ? wv::read_lane(py1, src) : wv::read_lane(py0, src);
                     p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
@@ -531,14 +536,14 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
                 for (int t = 0; t < T; ++t) {
                     const int src = t >> 1;
                     acc_a += (t & 1) ? wv::read_lane(st1, src) : wv::read_lane(st0, src);
-                    acc_b += (t & 1) ? wv::read_lane(st1, 32 + src) : wv::read_lane(st0, 32 + src);
+                    if (SPW == 2) acc_b += (t & 1) ? wv::read_lane(st1, 32 + src) : wv::read_lane(st0, 32 + src);
                 }
             } else {
-                const R part = wv::scan_incl_half<wv::OpAdd>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
-                acc_a = wv::read_lane(part, 31);
+                const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
+                acc_a = wv::read_lane(part, HL - 1);
                 acc_b = wv::read_lane(part, 63);
             }
-            total = h ? acc_b + wv::read_lane(term, 32 + lane_last) : acc_a + wv::read_lane(term, lane_last);
+            total = h ? acc_b + wv::read_lane(term, (SPW == 2 ? 32 : 0) + lane_last) : acc_a + wv::read_lane(term, lane_last);
         } else {  // `S[k] =`: only the last step's stage cost survives (:124)
             bool hit_l;
             const int idx_l = sub_last ? idx1 : idx0;
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
             if (hit_l) term += P.penalty;
             const R both = st_l + term;
-            total = h ? wv::read_lane(both, 32 + lane_last) : wv::read_lane(both, lane_last);
+            total = h ? wv::read_lane(both, (SPW == 2 ? 32 : 0) + lane_last) : wv::read_lane(both, lane_last);
         }
         S_k = total;
         if (l32 == 0 && live) {
@@ -559,12 +564,12 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     if (valid && !live) S_k = P.S[k];  // final from an earlier speculation round
     STAMP(2);
 
-    // ---- the workgroup's softmin record over its 32 samples (S5-S6) -----------------------------------------
-    const int sidx = wid * 2 + h;
+    // ---- the workgroup's softmin record over its samples (S5-S6) -----------------------------------------------
+    const int sidx = wid * SPW + h;
     if (l32 == 0) sh_S[sidx] = S_k;
     __syncthreads();
     STAMP(3);
-    const R rho = wv::read_lane(wv::scan_incl_half<wv::OpMin>(sh_S[l32]), 31);
+    const R rho = wv::read_lane(wv::scan_incl_seg<wv::OpMin, SPW>(l32 < SAMPLES ? sh_S[l32] : R(INFINITY)), HL - 1);
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
     if (l32 == 0) sh_e[sidx] = e;
     {
@@ -576,13 +581,13 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
         R acc = 0;
 #pragma unroll
-        for (int q = 0; q < DUAL_SAMPLES; ++q) acc += sh_acc[q][i];
+        for (int q = 0; q < SAMPLES; ++q) acc += sh_acc[q][i];
         out[4 + i] = acc;
     }
     if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
         R eta = 0, eta2 = 0;
 #pragma unroll
-        for (int q = 0; q < DUAL_SAMPLES; ++q) {
+        for (int q = 0; q < SAMPLES; ++q) {
             const R ew = sh_e[q];
             eta += ew;
             eta2 += ew * ew;
@@ -1360,15 +1365,23 @@ static bool dual_layout(int K, int T) {
     if (const char *e = getenv("MPPI_DUAL")) return atoi(e) != 0;
     return K >= 8192;
 }
+// 64 < T <= 128: one sample per wave, two steps per lane (k_rollout_dual<.., 1>) instead of two 64-step chunks
+static bool pair_layout(int T) {
+    if (T <= 64 || T > 128) return false;
+    if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
+    return true;
+}
 int fused_blocks(int K, int T) {
-    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES;
+    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES;  // (the pair layout: DUAL_WAVES = 16 too)
     return (K + per_block - 1) / per_block;
 }
 
 template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
     const dim3 grid(fused_blocks(P.K, P.T));
     if (dual_layout(P.K, P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+    else if (pair_layout(P.T))
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (P.T <= 64)
         hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
     else

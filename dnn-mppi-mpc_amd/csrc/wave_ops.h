@@ -67,6 +67,11 @@ template <typename Op, typename R> __device__ __forceinline__ R scan_incl_half(R
     return x;
 }
 
+// SEG segments per wave (1: the whole wave, 2: its 32-lane halves)
+template <typename Op, int SEG, typename R> __device__ __forceinline__ R scan_incl_seg(R x) {
+    return SEG == 2 ? scan_incl_half<Op>(x) : scan_incl<Op>(x);
+}
+
 // lane i <- x[i-1], lane 0 <- carry.
 template <typename R> __device__ __forceinline__ R shift_up1(R x, R carry) { return dpp<DPP_WAVE_SHR1>(x, carry); }
 
@@ -74,6 +79,10 @@ template <typename R> __device__ __forceinline__ R shift_up1(R x, R carry) { ret
 template <typename R> __device__ __forceinline__ R shift_up1_half(R x, R carry) {
     const R sh = dpp<DPP_WAVE_SHR1>(x, carry);
     return (lane_id() & 31) == 0 ? carry : sh;
+}
+
+template <int SEG, typename R> __device__ __forceinline__ R shift_up1_seg(R x, R carry) {
+    return SEG == 2 ? shift_up1_half(x, carry) : shift_up1(x, carry);
 }
 
 __device__ __forceinline__ float read_lane(float x, int lane) {
