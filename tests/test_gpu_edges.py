@@ -124,3 +124,77 @@ def test_checkpoint_resume_reproduces_the_run():
     ua = a._calc_input_control(x)[1].copy()
     ub = b._calc_input_control(x)[1].copy()
     np.testing.assert_array_equal(ua, ub)
+
+
+@pytest.mark.parametrize("pair", ["0", "1"])
+@pytest.mark.parametrize("K,T,obstacles", [(33, 65, 0), (100, 100, 2), (17, 128, 0), (300, 77, 1)])
+def test_long_horizon_layouts_match_oracle(monkeypatch, pair, K, T, obstacles):
+    """64 < T <= 128: two 64-step chunks per wave (MPPI_PAIR=0) and one pass with two steps per lane (=1)."""
+    import dnn_mppi_mpc_amd as pkg
+    monkeypatch.setenv("MPPI_PAIR", pair)
+    rng = np.random.default_rng(K * 977 + T)
+    kw = dd_case(rng, K, T, 100, obstacles)
+    eps = philox.sample_epsilon(kw["sigma"], K + T, 0, K, T)
+    x0 = np.array([rng.uniform(0, 1), rng.uniform(-0.5, 0.5), rng.uniform(-1, 1)])
+    u_in = rng.normal(0, 0.3, (T, 2))
+    o = mppi_oracle.DiffDriveOracle(**kw)
+    o.u_prev[:] = u_in
+    c = pkg.MPPIAlgorithms(**kw, precision="f64")
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: eps
+    ref = o.iteration(x0, eps.astype(np.float64))
+    u = c._calc_input_control(x0)[1]
+    S = c.sample_costs()
+    hit = ref["S"] > 1e9
+    np.testing.assert_array_equal(S > 1e9, hit)
+    np.testing.assert_allclose(S[~hit], ref["S"][~hit], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-7, atol=1e-9)
+    assert c.prev_way_point_idx == ref["idx_after"]
+
+
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_long_horizon_racecar(monkeypatch, pair):
+    import dnn_mppi_mpc_amd as pkg
+    monkeypatch.setenv("MPPI_PAIR", pair)
+    lem = mppi_oracle.generate_lemniscate_racecar(80, 10.0)
+    kw = dict(ref_path=lem, horizon_step_T=75, number_of_samples_K=150, param_exploration=0.1, param_alpha=0.9,
+              obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), visualize_optimal_traj=True,
+              visualze_sampled_trajs=False)
+    eps = philox.sample_epsilon(np.array([[0.5, 0.0], [0.0, 0.1]]), 11, 0, 150, 75)
+    o = mppi_oracle.RaceCarOracle(**kw)
+    c = pkg.MPPIRacecarController(**kw, precision="f32")
+    c._calc_epsilon = lambda *a, **k: eps
+    ref = o.iteration(lem[2], eps)
+    u = c._calc_control_input(lem[2])[1]
+    hit = ref["S"] > 1e9
+    np.testing.assert_allclose(c.sample_costs()[~hit], ref["S"][~hit], rtol=3e-5, atol=1e-3)
+    assert rmse(u, ref["u_returned"]) <= 1e-4
+
+
+def test_exchange_api_errors():
+    """mppi_comm_*: call-order and mode errors are reported, the handle stays usable."""
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    base = dict(model=capi.MODEL_DIFFDRIVE, K=64, T=20, delta_t=0.1, u_max=[1.0, 1.0], param_exploration=0.1,
+                param_lambda=1.0, param_alpha=0.5, sigma=[0.1, 0.0, 0.0, 0.1], stage_cost_weight=[1, 1, 1, 0],
+                terminal_cost_weight=[1, 1, 1, 0], search_window=20, filter_window=10, clamp_rollout=1)
+    seq = pkg.Engine(**base)  # sequential waypoint index: no exchange
+    with pytest.raises(pkg.MppiError) as ex:
+        seq.comm_export(2)
+    assert ex.value.code == capi.ERR_UNSUPPORTED
+    e = pkg.Engine(**dict(base, waypoint_mode=capi.WAYPOINT_FROZEN, K=32, K_global=64, k_offset=0))
+    with pytest.raises(pkg.MppiError) as ex:  # probe / connect before export
+        e.comm_probe()
+    assert ex.value.code == capi.ERR_STATE
+    with pytest.raises(pkg.MppiError) as ex:
+        e.comm_connect(0, [b"\0" * 64, b"\0" * 64])
+    assert ex.value.code == capi.ERR_STATE
+    with pytest.raises(pkg.MppiError) as ex:  # one rank is not an exchange
+        e.comm_export(1)
+    assert ex.value.code == capi.ERR_BAD_ARG
+    h = e.comm_export(2)
+    assert len(h) == 64 and e.comm_buffer()
+    e.comm_close()
+    e.set_ref_path(mppi_oracle.generate_point_trajectory((0, 0), (1, 1), 10))
+    # without a connected exchange the handle is an ordinary (sharded: use the split step) one
+    assert e.lib.mppi_comm_handle_bytes() == 64
