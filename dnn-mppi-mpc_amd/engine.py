@@ -51,6 +51,10 @@ class Engine:
             self._h = None
             capi.check(self.lib, None, rc)
         self.stats = capi.MppiStats()
+        # buffers and ctypes arguments of the per-iteration call, built once (every `.ctypes.data_as` costs ~1 us)
+        self._x0_buf = np.zeros(self.nx)
+        self._u_buf, self._u0_buf = np.empty((self.T, 2)), np.empty(2)
+        self._step_args = (_dp(self._x0_buf), _dp(self._u_buf), _dp(self._u0_buf), C.byref(self.stats))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -144,14 +148,16 @@ class Engine:
     def step(self, x0, eps=None, stream=None):
         """One MPPI iteration.  ``eps``: CUDA float32 tensor [K,T,2] or None (on-device Philox).
         Returns (u[T,2] shifted, u0[2], stats)."""
-        x0 = np.ascontiguousarray(x0, dtype=np.float64)
-        if x0.shape != (self.nx,):
+        if np.shape(x0) != (self.nx,):
             raise ValueError(f"observed_x must have {self.nx} entries")
-        self._check_eps(eps)
-        u, u0 = np.empty((self.T, 2)), np.empty(2)
-        self._ck(self.lib.mppi_step(self._h, _dp(x0), _dev_ptr(eps), _dp(u), _dp(u0), C.byref(self.stats),
-                                    _stream_ptr(stream)))
-        return u, u0, self.stats
+        self._x0_buf[:] = x0
+        if eps is not None:
+            self._check_eps(eps)
+        xp, up, u0p, stp = self._step_args
+        rc = self.lib.mppi_step(self._h, xp, _dev_ptr(eps), up, u0p, stp, _stream_ptr(stream))
+        if rc:
+            self._ck(rc)
+        return self._u_buf.copy(), self._u0_buf.copy(), self.stats
 
     def _check_eps(self, eps):
         if eps is not None:
