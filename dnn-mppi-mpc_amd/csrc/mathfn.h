@@ -54,7 +54,9 @@ __device__ __forceinline__ double exp_(double x) { return exp(x); }
 // fp32: a - m*floor(a/m) with one correction step instead of the exact iterative fmodf (a handful of ops instead of
 // ~60; it can differ from fmodf by an ulp of a, i.e. ~5e-7 rad on a wrapped yaw -- far inside the fp32 tolerance)
 __device__ __forceinline__ float pymod(float a, float m) {
-    float r = fmaf(-m, floorf(__fdividef(a, m)), a);
+    // (v_rcp_f32 + multiply: `__fdividef` compiles to the ten-instruction IEEE division without fast-math; an
+    // off-by-one floor near a multiple of m is what the two correction steps below absorb)
+    float r = fmaf(-m, floorf(a * __builtin_amdgcn_rcpf(m)), a);
     r = r < 0.f ? r + m : r;
     return r >= m ? r - m : r;
 }

@@ -728,7 +728,7 @@ template <typename A, int NT = MERGE_THREADS> struct MergeLds {
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
-__device__ __forceinline__ float fast_div(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // 1 ulp
 __device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
 
 template <typename A> struct BlockRed {  // block-wide reductions through one LDS exchange each (256 threads)
