@@ -505,7 +505,8 @@ static bool timing_on(const mppi_handle *h) { return h->timing && h->ev_used + E
 
 // Softmin partial records of this handle's samples: rollout (+ reduce when not fused), and for large K a
 // 64:1 merge so that the finalize block never reads more than MAX_FINAL_PARTS records.
-constexpr int MAX_FINAL_PARTS = 256;  // = MERGE_MAX_RECORDS of the kernels
+constexpr int MAX_FINAL_PARTS = 256;   // = MERGE_MAX_RECORDS of the kernels (ABI records: one per rank)
+constexpr int MAX_DIRECT_PARTS = 512;  // block records k_finalize merges itself (two windows of 256)
 
 static void launch_mlp(mppi_handle *h, const KParams<float> &P, hipStream_t s) {
     launch_rollout_mlp(P, h->mlp, h->d_partials, s);
@@ -528,7 +529,7 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     *recs = h->d_partials;
     *heads = h->d_heads;
     *n_recs = h->n_part;
-    if (h->n_part > MAX_FINAL_PARTS) {
+    if (h->n_part > MAX_DIRECT_PARTS) {
         const int group = h->n_part > 64 * MAX_FINAL_PARTS ? MAX_FINAL_PARTS : 64;
         launch_merge<R>(h->d_partials, h->d_heads, h->n_part, group, h->cfg.T, beta, h->d_partials2, h->d_heads2, false, s);
         *recs = h->d_partials2;
@@ -712,6 +713,12 @@ static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double
     h->dev_loop_primed = x0 == nullptr;
     h->slot_timed = timing_on(h);
     launch_front<R>(h, P, F.beta, s, &recs, &heads, &n_recs, h->slot_timed);
+    if (n_recs > MAX_FINAL_PARTS) {  // (k_merge takes 256 records per workgroup)
+        launch_merge<R>(recs, heads, n_recs, 64, h->cfg.T, F.beta, h->d_partials2, h->d_heads2, false, s);
+        recs = h->d_partials2;
+        heads = h->d_heads2;
+        n_recs = (n_recs + 63) / 64;
+    }
     launch_merge<R>(recs, heads, n_recs, n_recs, h->cfg.T, F.beta, partial, nullptr, true, s);  // this rank's record (f64)
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;

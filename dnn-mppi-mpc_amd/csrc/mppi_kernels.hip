@@ -699,7 +699,8 @@ __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rh
 // the per-rank record of the split step uses the ABI layout {rho, eta, eta2, W[2T]} in doubles.
 // ------------------------------------------------------------------------------------------
 constexpr int MERGE_THREADS = 256;
-constexpr int MERGE_MAX_RECORDS = 256;
+constexpr int MERGE_MAX_RECORDS = 256;  // per window
+constexpr int MERGE_MAX_WINDOWS = 2;    // k_finalize takes up to 512 records itself (K = 16384 in the dual layout)
 // NT threads merge 256 records: thread = (16-byte column vc = tid % 32, group grp = tid / 32), NT/32 groups of
 // 256/(NT/32) consecutive records.  NT = 256: the merge kernels' own launches; NT = 1024: the prologue of k_iter.
 template <int NT> struct MergeShape {
@@ -713,7 +714,7 @@ template <typename A> struct alignas(16) VecT { A v[16 / sizeof(A)]; };
 // partial sums.  Every region starts on a 16-byte boundary.
 __host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem, int nt = MERGE_THREADS) {
     const size_t r4 = 3, nw = (2 * (size_t)(T + W + 1) + r4) & ~r4, nu = (2 * (size_t)T + r4) & ~r4;
-    return nw + nu + (size_t)nt + 64 + (size_t)(nt / 32) * 32 * (16 / elem);
+    return nw + nu + (size_t)MERGE_MAX_WINDOWS * nt + 64 + (size_t)(nt / 32) * 32 * (16 / elem);
 }
 template <typename A, int NT = MERGE_THREADS> struct MergeLds {
     A *w, *u, *s, *red, *part;
@@ -721,7 +722,7 @@ template <typename A, int NT = MERGE_THREADS> struct MergeLds {
         w = reinterpret_cast<A *>(smem);
         u = w + ((2 * (T + W + 1) + 3) & ~3);
         s = u + ((2 * T + 3) & ~3);
-        red = s + NT;
+        red = s + MERGE_MAX_WINDOWS * NT;
         part = red + 64;
     }
 };
@@ -755,7 +756,7 @@ template <typename A> struct BlockRed {  // block-wide reductions through one LD
     }
 };
 
-// Merge n <= 256 records with the rescale trick: rho = min rho_b,
+// Merge n <= 256 NWIN records with the rescale trick: rho = min rho_b,
 // s_b = exp(-beta (rho_b - rho)), eta = sum s_b eta_b, W = sum s_b W_b.  Records come from a PREVIOUS
 // launch: ordinary loads are coherent.  Written for latency -- the caller issues every load first thing
 // (merge_load_*), before it touches anything else, so that one memory round trip covers them all; the
@@ -763,16 +764,17 @@ template <typename A> struct BlockRed {  // block-wide reductions through one LD
 // Record b lives in slot b; slots >= n are never written by a producer and the buffers are zero-filled and
 // padded by 256 records at creation, so every load is unconditional and in bounds, and an absent slot enters
 // with a zero scale.
-template <typename A, int NT = MERGE_THREADS> struct MergeRegs {
-    VecT<A> w[MergeShape<NT>::MAXJ];
-    A hr[4], he[4], he2[4];  // heads of records lane, lane+64, lane+128, lane+192
+// NWIN windows of 256 records: the same thread mapping in every window, all windows' loads in flight at once.
+template <typename A, int NT = MERGE_THREADS, int NWIN = 1> struct MergeRegs {
+    VecT<A> w[NWIN][MergeShape<NT>::MAXJ];
+    A hr[4 * NWIN], he[4 * NWIN], he2[4 * NWIN];  // heads of records 256 win + lane + {0, 64, 128, 192}
 };
 
-template <typename A, int NT>
-__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT> &m) {
+template <typename A, int NT, int NWIN>
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT, NWIN> &m) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
+    for (int i = 0; i < 4 * NWIN; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
         const VecT4<A> hd = *reinterpret_cast<const VecT4<A> *>(heads + 4 * (size_t)(lane + 64 * i));
         m.hr[i] = hd.x;
         m.he[i] = hd.y;
@@ -780,8 +782,8 @@ __device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, Me
     }
 }
 
-template <typename A, int NT>
-__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT> &m) {
+template <typename A, int NT, int NWIN>
+__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT, NWIN> &m) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ;
     const int tid = threadIdx.x, vc = tid & 31, grp = tid >> 5;
     const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
@@ -789,13 +791,17 @@ __device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int 
     const char *base = reinterpret_cast<const char *>(recs);
     const unsigned off0 = (unsigned)(grp * MAXJ) * rbytes + (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) m.w[j] = *reinterpret_cast<const VecT<A> *>(base + (off0 + (unsigned)j * rbytes));
+    for (int win = 0; win < NWIN; ++win)
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            m.w[win][j] = *reinterpret_cast<const VecT<A> *>(base + (off0 + (unsigned)(win * MERGE_MAX_RECORDS + j) * rbytes));
 }
 
 // `store(i, v)` receives w_eps[i] = W[i] / eta for i in [0, 2T); rho/eta/eta2 end up in every thread.
-template <typename A, int NT, typename Store>
-__device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta, MergeRegs<A, NT> &m,
-                                              A *sh_s, A *sh_part, A &rho, A &eta, A &eta2, Store store) {
+template <typename A, int NT, int NWIN, typename Store>
+__device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta,
+                                              MergeRegs<A, NT, NWIN> &m, A *sh_s, A *sh_part, A &rho, A &eta, A &eta2,
+                                              Store store) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ, GROUPS = MergeShape<NT>::GROUPS;
     using V = VecT<A>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -803,17 +809,17 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
     const int nvc = (2 * T + VW - 1) / VW;
     A lr = A(INFINITY);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * NWIN; ++i) {
         if (lane + 64 * i >= n) m.hr[i] = A(INFINITY);
         lr = fmin(lr, m.hr[i]);
     }
     rho = wv::reduce<wv::OpMin>(lr);
     STAMP(25);
-    A sc[4];
+    A sc[4 * NWIN];
     eta = 0;
     eta2 = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * NWIN; ++i) {
         sc[i] = lane + 64 * i < n ? fast_exp(-beta * (m.hr[i] - rho)) : A(0);
         eta += sc[i] * m.he[i];
         eta2 += sc[i] * sc[i] * m.he2[i];
@@ -822,9 +828,12 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
     eta2 = wv::reduce<wv::OpAdd>(eta2);
     // this wave's two groups use the scales of records r0 .. r0 + 2 MAXJ - 1 only (a run inside one of the four
     // 64-record slots every lane holds): a wave-local exchange through 64 private LDS words, no block barrier
+    // (per window)
     const int r0 = wid * 2 * MAXJ, slot = r0 >> 6;
-    A *my_s = sh_s + wid * 64;
-    my_s[lane] = slot == 0 ? sc[0] : slot == 1 ? sc[1] : slot == 2 ? sc[2] : sc[3];
+    A *my_s = sh_s + wid * 64;  // window win at + win * NT
+#pragma unroll
+    for (int win = 0; win < NWIN; ++win)
+        my_s[win * NT + lane] = slot == 0 ? sc[4 * win] : slot == 1 ? sc[4 * win + 1] : slot == 2 ? sc[4 * win + 2] : sc[4 * win + 3];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -837,15 +846,17 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
 #pragma unroll
         for (int q = 0; q < VW; ++q) acc.v[q] = 0;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const A sj = sj_base[j];
+        for (int win = 0; win < NWIN; ++win)
 #pragma unroll
-            for (int q = 0; q < VW; ++q) acc.v[q] += sj * m.w[j].v[q];
-        }
+            for (int j = 0; j < MAXJ; ++j) {
+                const A sj = sj_base[win * NT + j];
+#pragma unroll
+                for (int q = 0; q < VW; ++q) acc.v[q] += sj * m.w[win][j].v[q];
+            }
         if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT>(recs, T, vt + 1, m);  // T > 64 only
+        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT, NWIN>(recs, T, vt + 1, m);  // T > 64 only
         for (int e = tid; e < 32 * VW; e += NT) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
@@ -897,11 +908,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     A *sh_w = L.w;
     const int b0 = blockIdx.x * group, nb = min(group, n - b0);
     const A *mine = recs + (size_t)b0 * record_len(T, (int)sizeof(A));
-    MergeRegs<A, MERGE_THREADS> mr;
-    merge_load_heads<A, MERGE_THREADS>(heads + 4 * (size_t)b0, mr);
-    merge_load_tile<A, MERGE_THREADS>(mine, T, 0, mr);
+    MergeRegs<A, MERGE_THREADS, 1> mr;
+    merge_load_heads<A, MERGE_THREADS, 1>(heads + 4 * (size_t)b0, mr);
+    merge_load_tile<A, MERGE_THREADS, 1>(mine, T, 0, mr);
     A rho, eta, eta2;
-    merge_combine<A, MERGE_THREADS>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
+    merge_combine<A, MERGE_THREADS, 1>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
     // merge_combine leaves W / eta; a record carries W itself
     if (ABI_OUT) {
         double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
@@ -967,7 +978,7 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 // workgroup of NT threads; state and controls are updated where they are or into F.st_out / F.u_out.
 // The *_pre arguments repeat F.partials, F.heads, F.st, F.u and F.T: leading kernel arguments that the dispatcher
 // preloads into SGPRs (-amdgpu-kernarg-preload-count), so the first loads do not wait for the argument fetch.
-template <typename A, int MODE, int NT>
+template <typename A, int MODE, int NT, int NWIN>
 __device__ __forceinline__ void finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
                                               const void *u_pre, int T_pre, const FinalizeParams &F, char *smem) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
@@ -993,10 +1004,10 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     static_assert(sizeof(DevState) == 72, "DevState layout");
     const int st_word = reinterpret_cast<const int *>(st_pre)[lane < 18 ? lane : 0];
     const A u_old = tid < 2 * T_pre ? u_in[tid] : A(0);  // elements >= NT: re-read below
-    MergeRegs<A, NT> mr;
+    MergeRegs<A, NT, NWIN> mr;
     if (!ABI_RECS) {
-        merge_load_heads<A, NT>(reinterpret_cast<const A *>(heads_pre), mr);
-        merge_load_tile<A, NT>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
+        merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
+        merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
     STAMP(24);
     DevState sv;
@@ -1092,12 +1103,12 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
     } else if (!XCHG) {
-        merge_combine<A, NT>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
-                             eta2, store_w);
+        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
+                                   eta, eta2, store_w);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
-        merge_combine<A, NT>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho, eta,
-                             eta2, [&](int i, A v) { sh_u[i] = v; });
+        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
+                                   eta, eta2, [&](int i, A v) { sh_u[i] = v; });
         const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(T, F.x_nranks);
         const size_t rec_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)F.x_rank * xchg_rec_len(T);
         for (int p = 0; p < F.x_nranks; ++p) {
@@ -1243,12 +1254,12 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     STAMP(21);
 }
 
-template <typename A, int MODE>
+template <typename A, int MODE, int NWIN>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
                                                             const DevState *st_pre, const void *u_pre, int T_pre,
                                                             const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    finalize_body<A, MODE, MERGE_THREADS>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem);
+    finalize_body<A, MODE, MERGE_THREADS, NWIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1415,12 +1426,14 @@ void launch_merge(const void *recs, const void *heads, int n, int group, int T, 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
     const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R));
     const DevState *st = F.st;
-    if (abi_recs)
-        hipLaunchKernelGGL((k_finalize<R, 1>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
-    else if (F.x_nranks > 1)
-        hipLaunchKernelGGL((k_finalize<R, 2>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
-    else
-        hipLaunchKernelGGL((k_finalize<R, 0>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st, (const void *)F.u, F.T, F);
+    const bool two = F.n_part > MERGE_MAX_RECORDS;  // (at most MERGE_MAX_WINDOWS * 256: the caller merges above that)
+#define MPPI_FIN(MODE, NWIN)                                                                                      \
+    hipLaunchKernelGGL((k_finalize<R, MODE, NWIN>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,  \
+                       (const void *)F.u, F.T, F)
+    if (abi_recs) MPPI_FIN(1, 1);
+    else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2); else MPPI_FIN(2, 1); }
+    else { if (two) MPPI_FIN(0, 2); else MPPI_FIN(0, 1); }
+#undef MPPI_FIN
 }
 
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) {
