@@ -123,12 +123,23 @@ template <typename R> __device__ __forceinline__ int window_len(int window, int 
 
 // collision indicator of one state (mppi_differential_drive_obs.py:301-313,
 // mppi_race_car_obstacle.py:241-274)
-template <typename R> __device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw) {
+// `obs`: P.obs, or the workgroup's LDS copy of it (stage_obstacles): after a kernel boundary the scalar cache is
+// cold, and 16 waves each walking the table with dependent scalar loads cost the launch microseconds
+constexpr int OBS_LDS_MAX = 64;
+template <typename R>
+__device__ __forceinline__ const R *stage_obstacles(R *sh_obs, const KParams<R> &P, int tid) {
+    if (P.obstacle_model == OBS_NONE || P.n_obs > OBS_LDS_MAX) return P.obs;
+    if (tid < 4 * P.n_obs) sh_obs[tid] = P.obs[tid];  // (the caller's barrier publishes it)
+    return sh_obs;
+}
+
+template <typename R>
+__device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, const R *__restrict__ obs) {
     bool hit = false;
     if (P.obstacle_model == OBS_CIRCLE) {
         for (int m = 0; m < P.n_obs; ++m) {
-            const R dx = x - P.obs[4 * m], dy = y - P.obs[4 * m + 1];
-            hit |= dx * dx + dy * dy < P.obs[4 * m + 2];
+            const R dx = x - obs[4 * m], dy = y - obs[4 * m + 1];
+            hit |= dx * dx + dy * dy < obs[4 * m + 2];
         }
     } else if (P.obstacle_model == OBS_OUTLINE) {
         R sn, cs;
@@ -138,8 +149,8 @@ template <typename R> __device__ __forceinline__ bool collided(const KParams<R> 
             const R px = P.shape_x[q] * cs - P.shape_y[q] * sn + x;
             const R py = P.shape_x[q] * sn + P.shape_y[q] * cs + y;
             for (int m = 0; m < P.n_obs; ++m) {
-                const R dx = px - P.obs[4 * m], dy = py - P.obs[4 * m + 1];
-                hit |= dx * dx + dy * dy < P.obs[4 * m + 2];
+                const R dx = px - obs[4 * m], dy = py - obs[4 * m + 1];
+                hit |= dx * dx + dy * dy < obs[4 * m + 2];
             }
         }
     }

@@ -93,14 +93,15 @@ template <typename R, int MODEL> struct Rollout {
     bool slow;             // sequential mode: some call moved the index, evolve it call by call
     R s_acc, s_last;
     const int n_chunk, lane_last;
-    const RefPair<R> *win;  // frozen-index modes: the search window staged in LDS by the workgroup (or null)
+    const RefPair<R> *win;  // the search window at c staged in LDS by the workgroup (or null)
+    const R *obs;           // obstacle table: P.obs or its LDS copy
 
     __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_,
-                                       const RefPair<R> *win_ = nullptr)
+                                       const RefPair<R> *win_, const R *obs_)
         : P(P_), k(k_), lane(lane_), c(sv.c), iter((unsigned)sv.iter),
           exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)sv.x0[0]), cy((R)sv.x0[1]), cyaw((R)sv.x0[2]),
           cvel(MODEL == MODEL_RACE ? (R)sv.x0[3] : R(0)), p(sv.c), slow(false), s_acc(0), s_last(0),
-          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63), win(win_) {}
+          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63), win(win_), obs(obs_) {}
 
     // this lane's noise for step t of sample k (S1, or the caller's tensor)
     __device__ __forceinline__ void load_eps(int ch, float &e0, float &e1) const {
@@ -204,7 +205,7 @@ template <typename R, int MODEL> struct Rollout {
         // ---- stage cost of every call (only the last one survives when !accumulate) ------
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
-            const bool hit = collided(P, x, y, yaw);
+            const bool hit = collided(P, x, y, yaw, obs);
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, my_idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
@@ -259,14 +260,16 @@ __global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const K
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
     const DevState sv = load_state(P, st_pre);
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    __shared__ R sh_obs[4 * OBS_LDS_MAX];
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
-    if (use_win) {
-        stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-        __syncthreads();
-    }
+    if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+    // (the obstacle table in LDS pays for the race car's 8 outline points x circles; the diff-drive kernels keep the
+    // scalar loads -- a generic pointer there costs registers and 0.2 us at config 2)
+    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;
+    __syncthreads();
     if (k >= P.K || k < sv.k_start) return;
-    Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr);
+    Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs);
     for (int ch = 0; ch < r.n_chunk; ++ch) {
         float e0, e1;
         r.chunk(ch, e0, e1);
@@ -296,18 +299,19 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     STAMP(1);
     const bool valid = k < P.K;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    __shared__ R sh_obs[4 * OBS_LDS_MAX];
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
-    if (use_win) {
-        stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-        __syncthreads();
-    }
+    const bool stage_obs = MODEL == MODEL_RACE && P.obstacle_model != OBS_NONE && P.n_obs <= OBS_LDS_MAX;
+    if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;  // (see k_rollout)
+    if (use_win || stage_obs) __syncthreads();
     float e0[NCH], e1[NCH];
     R S_k = R(INFINITY);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr);
+        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs);
         if (k >= k_start) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
@@ -390,12 +394,13 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     const int T = P.T, t0 = 2 * l32, t1 = t0 + 1;
     const bool a0 = t0 < T, a1 = t1 < T;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    __shared__ R sh_obs[4 * OBS_LDS_MAX];
     const int wlen0 = window_len<R>(P.window, P.n_ref, c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
-    if (use_win) {
-        stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-        __syncthreads();
-    }
+    const bool stage_obs = MODEL == MODEL_RACE && P.obstacle_model != OBS_NONE && P.n_obs <= OBS_LDS_MAX;
+    if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
+    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;  // (see k_rollout)
+    if (use_win || stage_obs) __syncthreads();
 
     // ---- S1: this lane's noise for its two steps ---------------------------------------------------------
     float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel>
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
 
         // ---- costs -----------------------------------------------------------------------------------------------
         auto stage_cost = [&](R x, R y, R yaw, R vel, int idx, R ua, R ub, R va, R vb, bool &hit) {
-            hit = collided(P, x, y, yaw);
+            hit = collided(P, x, y, yaw, obs);
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;

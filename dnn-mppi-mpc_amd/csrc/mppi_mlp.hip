@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
             }
             if (P.sequential) p = idx;
             if (P.accumulate || t == P.T - 1) {
-                const bool hit = collided(P, x, y, yaw);
+                const bool hit = collided(P, x, y, yaw, P.obs);
                 float st_c = tracking_cost<float, MODEL_DIFF>(P, P.ws, P.wrap_stage, idx, x, y, yaw, 0.f);
                 if (hit) st_c += P.penalty;
                 const float ctrl = (u0 * P.sinv[0] + u1 * P.sinv[2]) * v0 + (u0 * P.sinv[1] + u1 * P.sinv[3]) * v1;
