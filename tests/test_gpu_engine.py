@@ -173,6 +173,57 @@ def test_shard_invariance_two_shards_one_gpu():
         np.testing.assert_allclose(np.concatenate([e.costs() for e in parts]), whole.costs(), rtol=1e-12)
 
 
+def test_peer_exchange_three_shards_in_one_process():
+    """The peer-to-peer exchange with the peers living in this process (`local_ptrs` of mppi_comm_connect): three
+    handles own 1000 / 1000 / 1000 of K = 3000 samples, each runs its closed loop from its own host thread and stream,
+    and every finalize kernel waits for the other two.  All three must end where the unsharded handle ends."""
+    import threading
+
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    base = dict(model=capi.MODEL_RACECAR, T=40, delta_t=0.05, u_max=[0.523, 2.0], wheel_base=2.5,
+                param_exploration=0.1, param_lambda=50.0, param_alpha=0.9, sigma=[0.5, 0.0, 0.0, 0.1],
+                stage_cost_weight=[50.0, 50.0, 1.0, 20.0], terminal_cost_weight=[50.0, 50.0, 1.0, 20.0],
+                beta_mode=capi.BETA_INV_LAMBDA, accumulate_stage_cost=1, waypoint_mode=capi.WAYPOINT_FROZEN,
+                search_window=200, wrap_yaw_stage=1, wrap_yaw_terminal=1, clamp_rollout=1, clamp_u_after_update=1,
+                filter_mode=capi.FILTER_RACECAR, filter_window=10, obstacle_model=capi.OBSTACLE_NONE,
+                collision_penalty=1e10, seed=4242, precision=capi.PREC_F64)
+    K, n_it = 3000, 6
+    whole = pkg.Engine(K=K, **base)
+    parts = [pkg.Engine(K=1000, K_global=K, k_offset=1000 * r, **base) for r in range(3)]
+    for e in [whole] + parts:
+        e.set_ref_path(lem)
+        e.set_state(lem[2].astype(np.float64))
+    handles = [e.comm_export(3) for e in parts]
+    ptrs = [e.comm_buffer() for e in parts]
+    for r, e in enumerate(parts):
+        e.comm_connect(r, handles, local_ptrs=[None if q == r else ptrs[q] for q in range(3)])
+    streams = [torch.cuda.Stream() for _ in parts]
+    errs = []
+
+    def run(e, s):
+        try:
+            e.comm_probe(s)
+            e.run_closed_loop(n_it, stream=s)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ths = [threading.Thread(target=run, args=(e, s)) for e, s in zip(parts, streams)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not errs, errs
+    whole.run_closed_loop(n_it)
+    for e in parts:
+        np.testing.assert_allclose(e.get_u_prev(), whole.get_u_prev(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(e.get_state(), whole.get_state(), rtol=1e-9, atol=1e-12)
+        e.comm_close()
+
+
 def test_softmin_shift_and_permutation_invariance():
     """Adding a constant to every cost leaves the update unchanged; permuting the samples (with their
     noise rows) leaves the weighted reduce unchanged."""
