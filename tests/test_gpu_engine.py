@@ -224,6 +224,59 @@ def test_peer_exchange_three_shards_in_one_process():
         e.comm_close()
 
 
+def test_peer_exchange_missing_rank_times_out(monkeypatch):
+    """A rank that never arrives: the others give up after MPPI_EXCHANGE_TIMEOUT_MS with MPPI_ERR_COMM (no hang), the
+    failure is sticky for the queued iterations, and mppi_comm_close gives the handle back."""
+    import threading
+
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    monkeypatch.setenv("MPPI_EXCHANGE_TIMEOUT_MS", "200")
+    base = dict(model=capi.MODEL_DIFFDRIVE, T=20, delta_t=0.1, u_max=[1.0, 1.0], param_exploration=0.1,
+                param_lambda=1.0, param_alpha=0.5, sigma=[0.1, 0.0, 0.0, 0.1], stage_cost_weight=[1, 1, 1, 0],
+                terminal_cost_weight=[1, 1, 1, 0], search_window=20, filter_window=10, clamp_rollout=1,
+                waypoint_mode=capi.WAYPOINT_FROZEN)
+    parts = [pkg.Engine(K=64, K_global=192, k_offset=64 * r, **base) for r in range(3)]
+    ref = mppi_oracle.generate_point_trajectory((0, 0), (3, 1), 50)
+    for e in parts:
+        e.set_ref_path(ref)
+        e.set_state(np.zeros(3))
+    handles = [e.comm_export(3) for e in parts]
+    ptrs = [e.comm_buffer() for e in parts]
+    for r, e in enumerate(parts):
+        e.comm_connect(r, handles, local_ptrs=[None if q == r else ptrs[q] for q in range(3)])
+    codes = []
+
+    def run(e, s):
+        try:
+            e.run_closed_loop(5, stream=s)
+            codes.append(0)
+        except pkg.MppiError as ex:
+            codes.append(ex.code)
+
+    ths = [threading.Thread(target=run, args=(e, torch.cuda.Stream())) for e in parts[:2]]  # rank 2 stays away
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=60)
+    assert codes == [capi.ERR_COMM, capi.ERR_COMM]
+    with pytest.raises(pkg.MppiError) as ex:  # sticky until the exchange is closed
+        parts[0].run_closed_loop(1)
+    assert ex.value.code == capi.ERR_COMM
+    for e in parts:
+        e.comm_close()
+    import torch as _t
+    n = parts[0].partial_len()  # and the handle works again through the split step
+    gathered = _t.empty(3 * n, dtype=_t.float64, device="cuda")
+    for r, e in enumerate(parts):
+        e.step_begin(np.zeros(3), None, gathered[r * n:(r + 1) * n])
+    us = [e.step_end(gathered, 3)[0] for e in parts]
+    np.testing.assert_allclose(us[0], us[1], rtol=0, atol=0)
+    np.testing.assert_allclose(us[0], us[2], rtol=0, atol=0)
+
+
 def test_softmin_shift_and_permutation_invariance():
     """Adding a constant to every cost leaves the update unchanged; permuting the samples (with their
     noise rows) leaves the weighted reduce unchanged."""
