@@ -15,6 +15,7 @@ constexpr int STATUS_DONE = 0, STATUS_NEED_ROUND = 1, STATUS_PATH_END = 2, STATU
 // two slots (iteration parity), each {long long flag[XCHG_MAX_RANKS]; double rec[nranks][xchg_rec_len(T)]}.
 // Rank r owns flag[r] / rec[r] of every buffer.
 constexpr int XCHG_MAX_RANKS = 64;
+constexpr int XCHG_LDS_RANKS = 16;  // up to this many ranks' records are staged in LDS before they are merged
 __host__ __device__ inline int xchg_rec_len(int T) { return (3 + 2 * T + 1) & ~1; }
 __host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
     return sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)nranks * xchg_rec_len(T);

@@ -1129,6 +1129,15 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             return leave();
         }
         const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
+        if (F.x_nranks <= XCHG_LDS_RANKS) {
+            // the exchange buffer is fine-grained (uncached) memory: fetch all ranks' records with independent,
+            // coalesced loads -- one memory round trip -- instead of one dependent load per rank in the merge loop
+            double *sh_x = reinterpret_cast<double *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));
+            const int tot = F.x_nranks * xchg_rec_len(T);
+            for (int i = tid; i < tot; i += NT) sh_x[i] = recs[i];
+            __syncthreads();
+            recs = sh_x;
+        }
         merge_abi<A>(recs, F.x_nranks, T, (A)F.beta, L.s, L.red, rho, eta, eta2, store_w, xchg_rec_len(T));
     }
     STAMP(18);
@@ -1429,7 +1438,9 @@ void launch_merge(const void *recs, const void *heads, int n, int group, int T, 
 }
 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
-    const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R));
+    // (+ the staging area of the peer-to-peer exchange; merge_lds_elems is a multiple of 4 elements: 16-byte aligned)
+    const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R)) +
+                       (F.x_nranks > 1 ? sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(F.T) : 0);
     const DevState *st = F.st;
     const bool two = F.n_part > MERGE_MAX_RECORDS;  // (at most MERGE_MAX_WINDOWS * 256: the caller merges above that)
 #define MPPI_FIN(MODE, NWIN)                                                                                      \
