@@ -936,13 +936,26 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
 // raise this rank's flag in every rank's buffer (release: the records stored before the preceding barrier
 // are visible to whoever sees the flag), then wait for every rank's flag in the own buffer.  Returns false
 // after F.x_timeout ticks without them (and makes that sticky).  Every thread of the block calls this.
-__device__ __forceinline__ bool exchange_flags(const FinalizeParams &F, size_t slot_off) {
+// `peer_ptr`: lane p (< x_nranks) of every wave holds the base of rank p's exchange buffer, fetched once up front
+// (F.x_peers lives in device memory: indexing it inside the loops below would put a dependent load before every store)
+__device__ __forceinline__ char *peer_base(unsigned long long peer_ptr, int p) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)peer_ptr, p);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(peer_ptr >> 32), p);
+    return reinterpret_cast<char *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long load_peer_ptrs(const FinalizeParams &F) {
+    const int lane = threadIdx.x & 63;
+    return lane < F.x_nranks ? reinterpret_cast<unsigned long long>(F.x_peers[lane]) : 0ull;
+}
+
+__device__ __forceinline__ bool exchange_flags(const FinalizeParams &F, unsigned long long peer_ptr, size_t slot_off) {
     const int tid = threadIdx.x;
+    char *own = peer_base(peer_ptr, F.x_rank);
     __syncthreads();
-    if (tid < F.x_nranks) {
-        long long *theirs = reinterpret_cast<long long *>(F.x_peers[tid] + slot_off) + F.x_rank;
+    if (tid < F.x_nranks) {  // (wave 0: tid == lane, so peer_ptr is this thread's peer)
+        long long *theirs = reinterpret_cast<long long *>(reinterpret_cast<char *>(peer_ptr) + slot_off) + F.x_rank;
         __hip_atomic_store(theirs, F.x_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const long long *mine = reinterpret_cast<const long long *>(F.x_peers[F.x_rank] + slot_off) + tid;
+        const long long *mine = reinterpret_cast<const long long *>(own + slot_off) + tid;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != F.x_seq) {
             if (wall_clock64() - t0 > (unsigned long long)F.x_timeout) {
@@ -964,12 +977,13 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
     const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(F.T, F.x_nranks);
     const size_t recs_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS;
     auto pattern = [&](int rank, int i) { return (double)(F.x_seq * 4096 + rank * 64 + i); };
+    const unsigned long long peer_ptr = load_peer_ptrs(F);
     for (int p = 0; p < F.x_nranks; ++p) {
-        double *rec = reinterpret_cast<double *>(F.x_peers[p] + recs_off) + (size_t)F.x_rank * xchg_rec_len(F.T);
+        double *rec = reinterpret_cast<double *>(peer_base(peer_ptr, p) + recs_off) + (size_t)F.x_rank * xchg_rec_len(F.T);
         if (tid < n_chk) rec[tid] = pattern(F.x_rank, tid);
     }
-    bool ok = exchange_flags(F, slot_off);
-    const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + recs_off);
+    bool ok = exchange_flags(F, peer_ptr, slot_off);
+    const double *recs = reinterpret_cast<const double *>(peer_base(peer_ptr, F.x_rank) + recs_off);
     bool match = true;
     for (int r = 0; r < F.x_nranks; ++r)
         if (tid < n_chk) match &= recs[(size_t)r * xchg_rec_len(F.T) + tid] == pattern(r, tid);
@@ -1009,6 +1023,8 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     static_assert(sizeof(DevState) == 72, "DevState layout");
     const int st_word = reinterpret_cast<const int *>(st_pre)[lane < 18 ? lane : 0];
     const A u_old = tid < 2 * T_pre ? u_in[tid] : A(0);  // elements >= NT: re-read below
+    unsigned long long peer_ptr = 0;
+    if (XCHG) peer_ptr = load_peer_ptrs(F);
     MergeRegs<A, NT, NWIN> mr;
     if (!ABI_RECS) {
         merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
@@ -1117,18 +1133,18 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(T, F.x_nranks);
         const size_t rec_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)F.x_rank * xchg_rec_len(T);
         for (int p = 0; p < F.x_nranks; ++p) {
-            double *rec = reinterpret_cast<double *>(F.x_peers[p] + rec_off);
+            double *rec = reinterpret_cast<double *>(peer_base(peer_ptr, p) + rec_off);
             for (int i = tid; i < 2 * T; i += NT) rec[3 + i] = (double)(sh_u[i] * eta);  // W itself
             if (tid == 0) { rec[0] = (double)rho; rec[1] = (double)eta; rec[2] = (double)eta2; }
         }
-        if (!exchange_flags(F, slot_off)) {  // a peer never arrived: nothing is updated
+        if (!exchange_flags(F, peer_ptr, slot_off)) {  // a peer never arrived: nothing is updated
             if (tid == 0) {
                 res->status = STATUS_EXCHANGE_FAILED;
                 res->rounds = round + 1; res->iter = iter;
             }
             return leave();
         }
-        const double *recs = reinterpret_cast<const double *>(F.x_peers[F.x_rank] + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
+        const double *recs = reinterpret_cast<const double *>(peer_base(peer_ptr, F.x_rank) + slot_off + sizeof(long long) * XCHG_MAX_RANKS);
         if (F.x_nranks <= XCHG_LDS_RANKS) {
             // the exchange buffer is fine-grained (uncached) memory: fetch all ranks' records with independent,
             // coalesced loads -- one memory round trip -- instead of one dependent load per rank in the merge loop
