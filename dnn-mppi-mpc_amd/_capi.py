@@ -34,7 +34,7 @@ class MppiConfig(C.Structure):
         ("clamp_rollout", C.c_int32), ("clamp_u_after_update", C.c_int32), ("filter_mode", C.c_int32),
         ("filter_window", C.c_int32), ("obstacle_model", C.c_int32), ("raise_at_path_end", C.c_int32),
         ("safety_margin", C.c_double), ("vehicle_w", C.c_double), ("vehicle_l", C.c_double),
-        ("collision_penalty", C.c_double), ("seed", C.c_uint64),
+        ("collision_penalty", C.c_double), ("seed", C.c_uint64), ("n_agents", C.c_int32), ("noise_stream", C.c_int32),
     ]
 
 
@@ -116,7 +116,7 @@ def load_library(path: str | None = None):
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != 1:
+    if lib.mppi_abi_version() != 2:
         raise MppiError(ERR_BAD_ARG, "ABI version mismatch between _capi.py and libmppi_hip.so")
     if path is None:
         _lib = lib

@@ -22,6 +22,8 @@ struct mppi_handle {
     int nx = 3, n_ref = 0, n_obs = 0, n_blocks = 0, traj_per_block = 0;
     bool fused = false;       // rollout + softmin partial in one launch (T <= 128)
     int n_part = 0;           // records the rollout/reduce stage leaves in d_partials
+    int B = 1;                // agents (mppi_config.n_agents); per-agent buffers are B consecutive copies
+    int slots = 0;            // records per agent in d_partials / d_heads (n_part + zero padding)
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
     void *d_heads = nullptr, *d_heads2 = nullptr;  // compact {rho, eta, eta2, 0} of d_partials / d_partials2
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
@@ -139,6 +141,15 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
         FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
              "the sequential waypoint index threads through all samples in order and cannot be sharded; "
              "use MPPI_WAYPOINT_FROZEN with K_global > K");
+    if (c.n_agents < 1) c.n_agents = 1;
+    if (c.n_agents > 1) {
+        if (c.n_agents > 4096) FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: n_agents %d > 4096", c.n_agents);
+        if (c.waypoint_mode != MPPI_WAYPOINT_FROZEN || c.K_global != c.K || c.model == MPPI_MODEL_DIFFDRIVE_MLP ||
+            !fused_supported(c.T) || fused_blocks(c.K, c.T) > 512)
+            FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
+                 "several agents per handle need MPPI_WAYPOINT_FROZEN, an analytic model, T <= 128, at most 512 "
+                 "rollout workgroups (K <= 8192) and no sharding");
+    }
     const double det = c.sigma[0] * c.sigma[3] - c.sigma[1] * c.sigma[2];
     if (!(c.sigma[0] > 0) || !(det > 0))
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "sigma must be a symmetric positive definite 2x2 matrix");
@@ -181,14 +192,18 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(c.device)) != hipSuccess) return fail(e, "hipSetDevice");
-    const size_t r = rsz(h);
-    if ((e = hipMalloc(&h->d_u, r * 2 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u)");
-    if ((e = hipMalloc(&h->d_uhist, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
-    if ((e = hipMalloc(&h->d_S, r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
-    if ((e = hipMalloc((void **)&h->d_pout, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
+    const size_t r = rsz(h), B = (size_t)c.n_agents;
+    h->B = c.n_agents;
+    if (c.n_agents > 1 && getenv("MPPI_FORCE_UNFUSED"))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED, "several agents per handle need the fused rollout kernels");
+    if ((e = hipMalloc(&h->d_u, B * r * 2 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u)");
+    if ((e = hipMalloc(&h->d_uhist, B * r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
+    if ((e = hipMalloc(&h->d_S, B * r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
+    if ((e = hipMalloc((void **)&h->d_pout, B * sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
     const size_t rec_bytes = sizeof(double) * (size_t)record_len(c.T, 8);  // enough for either precision
     // zero-filled and padded by 256 records: the merge kernels read 256 slots unconditionally
-    const size_t n1 = (size_t)h->n_part + 256, n2 = (size_t)h->n_part / 64 + 2 + 256;
+    const size_t slots = (size_t)h->n_part + 256, n1 = B * slots, n2 = (size_t)h->n_part / 64 + 2 + 256;
+    h->slots = (int)slots;
     if ((e = hipMalloc(&h->d_partials, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMalloc(partials)");
     if ((e = hipMalloc(&h->d_partials2, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMalloc(partials2)");
     if ((e = hipMemset(h->d_partials, 0, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMemset");
@@ -197,22 +212,24 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_heads2, 32 * n2)) != hipSuccess) return fail(e, "hipMalloc(heads2)");
     if ((e = hipMemset(h->d_heads, 0, 32 * n1)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_heads2, 0, 32 * n2)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMalloc((void **)&h->d_st, sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
-    if ((e = hipMalloc((void **)&h->d_res, h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
-    if ((e = hipHostMalloc((void **)&h->h_res, h->res_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+    h->res_bytes = (h->res_bytes + 15) & ~(size_t)15;  // (the agents' results are stored back to back)
+    if ((e = hipMalloc((void **)&h->d_st, B * sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
+    if ((e = hipMalloc((void **)&h->d_res, B * h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
+    if ((e = hipHostMalloc((void **)&h->h_res, B * h->res_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return fail(e, "hipHostMalloc(result)");
     if ((e = hipHostGetDevicePointer((void **)&h->res_mapped, h->h_res, 0)) != hipSuccess)
         return fail(e, "hipHostGetDevicePointer(result)");
     h->poll = !getenv("MPPI_NO_POLL");
-    if ((e = hipMemset(h->d_u, 0, r * 2 * c.T)) != hipSuccess) return fail(e, "hipMemset");        // u_prev = 0 (:82)
-    if ((e = hipMemset(h->d_uhist, 0, r * 4 * c.T)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMemset(h->d_S, 0, r * c.K)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMemset(h->d_pout, 0, sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_u, 0, B * r * 2 * c.T)) != hipSuccess) return fail(e, "hipMemset");    // u_prev = 0 (:82)
+    if ((e = hipMemset(h->d_uhist, 0, B * r * 4 * c.T)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_S, 0, B * r * c.K)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(h->d_pout, 0, B * sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMemset");
     DevState st0;
     memset(&st0, 0, sizeof(st0));  // prev_way_point_idx = 0 (:85)
     st0.first_k = NO_TRIGGER;
-    if ((e = hipMemcpy(h->d_st, &st0, sizeof(st0), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-    memset(h->h_res, 0, h->res_bytes);
+    for (size_t a = 0; a < B; ++a)
+        if ((e = hipMemcpy(h->d_st + a, &st0, sizeof(st0), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    memset(h->h_res, 0, B * h->res_bytes);
     if ((e = hipEventCreate(&h->ev_step[0])) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev_step[1])) != hipSuccess) return fail(e, "hipEventCreate");
     *out = h;
@@ -316,14 +333,14 @@ extern "C" int mppi_set_u_prev(mppi_handle *h, const double *u) {
     if (!h || !u) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_u_prev: null argument");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    return upload_real(h, h->d_u, u, (size_t)2 * h->cfg.T);
+    return upload_real(h, h->d_u, u, (size_t)h->B * 2 * h->cfg.T);  // [n_agents][T][2]
 }
 
 extern "C" int mppi_get_u_prev(mppi_handle *h, double *u) {
     if (!h || !u) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_get_u_prev: null argument");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    return download_real(h, u, h->d_u, (size_t)2 * h->cfg.T);
+    return download_real(h, u, h->d_u, (size_t)h->B * 2 * h->cfg.T);  // [n_agents][T][2]
 }
 
 extern "C" int mppi_set_waypoint_idx(mppi_handle *h, int32_t idx) {
@@ -331,7 +348,8 @@ extern "C" int mppi_set_waypoint_idx(mppi_handle *h, int32_t idx) {
     if (idx < 0 || (h->n_ref > 0 && idx >= h->n_ref)) FAIL(h, MPPI_ERR_BAD_ARG, "waypoint index %d out of range", idx);
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    HIPCHECK(h, hipMemcpy(&h->d_st->p, &idx, sizeof(int), hipMemcpyHostToDevice));
+    for (int a = 0; a < h->B; ++a)  // (every agent of a batched handle)
+        HIPCHECK(h, hipMemcpy(&h->d_st[a].p, &idx, sizeof(int), hipMemcpyHostToDevice));
     h->idx = idx;
     return MPPI_OK;
 }
@@ -350,29 +368,34 @@ extern "C" int mppi_set_iteration(mppi_handle *h, int64_t iteration) {
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
     long long it = iteration;
-    HIPCHECK(h, hipMemcpy(&h->d_st->iter, &it, sizeof(it), hipMemcpyHostToDevice));
+    for (int a = 0; a < h->B; ++a)
+        HIPCHECK(h, hipMemcpy(&h->d_st[a].iter, &it, sizeof(it), hipMemcpyHostToDevice));
     h->iter = it;
     return MPPI_OK;
 }
 
-extern "C" int mppi_set_state(mppi_handle *h, const double *x) {
+extern "C" int mppi_set_state(mppi_handle *h, const double *x) {  // x: [n_agents][nx]
     if (!h || !x) return MPPI_ERR_BAD_ARG;
-    double v[4] = {0, 0, 0, 0};
-    for (int i = 0; i < h->nx; ++i) v[i] = x[i];
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    HIPCHECK(h, hipMemcpy(h->d_st->x0, v, sizeof(v), hipMemcpyHostToDevice));
+    for (int a = 0; a < h->B; ++a) {
+        double v[4] = {0, 0, 0, 0};
+        for (int i = 0; i < h->nx; ++i) v[i] = x[(size_t)a * h->nx + i];
+        HIPCHECK(h, hipMemcpy(h->d_st[a].x0, v, sizeof(v), hipMemcpyHostToDevice));
+    }
     h->dev_loop_primed = false;
     return MPPI_OK;
 }
 
-extern "C" int mppi_get_state(mppi_handle *h, double *x) {
+extern "C" int mppi_get_state(mppi_handle *h, double *x) {  // x: [n_agents][nx]
     if (!h || !x) return MPPI_ERR_BAD_ARG;
-    double v[4];
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    HIPCHECK(h, hipMemcpy(v, h->d_st->x0, sizeof(v), hipMemcpyDeviceToHost));
-    for (int i = 0; i < h->nx; ++i) x[i] = v[i];
+    for (int a = 0; a < h->B; ++a) {
+        double v[4];
+        HIPCHECK(h, hipMemcpy(v, h->d_st[a].x0, sizeof(v), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->nx; ++i) x[(size_t)a * h->nx + i] = v[i];
+    }
     return MPPI_OK;
 }
 
@@ -442,6 +465,9 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.S = (R *)h->d_S;
     P.pout = h->d_pout;
     P.st = h->d_st;
+    P.noise_stream = c.noise_stream;
+    P.slots = h->slots;
+    P.n_agents = h->B;
     P.heads = (R *)h->d_heads;
     return P;
 }
@@ -481,6 +507,9 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.st = h->d_st;
     F.st_out = h->d_st;
     F.res = h->d_res;
+    F.slots = h->slots;
+    F.n_agents = h->B;
+    F.res_stride = h->res_bytes;
     F.u0_trace = nullptr;
     return F;
 }
@@ -594,6 +623,12 @@ static int check_ready(mppi_handle *h, const char *who) {
     return MPPI_OK;
 }
 
+// entry points that serve one agent only (the host-in-the-loop and split steps, visualisation, the exchange)
+#define SINGLE_AGENT_ONLY(h, who)                                                                                     \
+    do {                                                                                                              \
+        if ((h)->B > 1) FAIL(h, MPPI_ERR_UNSUPPORTED, "%s serves single-agent handles (n_agents = %d)", who, (h)->B); \
+    } while (0)
+
 static void fill_stats(const mppi_handle *h, mppi_stats *stats) {
     if (!stats) return;
     const StepResult *r = h->h_res;
@@ -688,6 +723,7 @@ extern "C" int mppi_step(mppi_handle *h, const double *x0, const float *eps, dou
                          mppi_stats *stats, void *stream) {
     int rc = check_ready(h, "mppi_step");
     if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_step");
     if (!x0) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step: x0 is null");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     double x[4] = {0, 0, 0, 0};
@@ -730,6 +766,7 @@ static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double
 extern "C" int mppi_step_begin(mppi_handle *h, const double *x0, const float *eps, double *partial, void *stream) {
     int rc = check_ready(h, "mppi_step_begin");
     if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_step_begin");
     if (!partial) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_begin: null argument");
     if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
         FAIL(h, MPPI_ERR_UNSUPPORTED, "the split step needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
@@ -745,6 +782,7 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
                              mppi_stats *stats, void *stream) {
     int rc = check_ready(h, "mppi_step_end");
     if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_step_end");
     if (!partials || nranks < 1 || nranks > MAX_FINAL_PARTS)
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end: bad partials/nranks (1..%d)", MAX_FINAL_PARTS);
     if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end without mppi_step_begin");
@@ -772,6 +810,7 @@ extern "C" int mppi_step_end(mppi_handle *h, const double *partials, int32_t nra
 extern "C" int mppi_step_end_async(mppi_handle *h, const double *partials, int32_t nranks, void *stream) {
     int rc = check_ready(h, "mppi_step_end_async");
     if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_step_end_async");
     if (!partials || nranks < 1 || nranks > MAX_FINAL_PARTS)
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_end_async: bad partials/nranks (1..%d)", MAX_FINAL_PARTS);
     if (!h->begun) FAIL(h, MPPI_ERR_STATE, "mppi_step_end_async without mppi_step_begin");
@@ -807,11 +846,12 @@ extern "C" int mppi_get_costs(mppi_handle *h, double *S) {
     if (!h || !S) return MPPI_ERR_BAD_ARG;
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    return download_real(h, S, h->d_S, (size_t)h->cfg.K);
+    return download_real(h, S, h->d_S, (size_t)h->B * h->cfg.K);  // [n_agents][K]
 }
 
 extern "C" int mppi_get_weights(mppi_handle *h, double *w) {
     if (!h || !w) return MPPI_ERR_BAD_ARG;
+    SINGLE_AGENT_ONLY(h, "mppi_get_weights");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     if (!h->d_w) HIPCHECK(h, hipMalloc((void **)&h->d_w, sizeof(double) * h->cfg.K));
     if (h->f64) {
@@ -831,7 +871,7 @@ extern "C" int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     KParams<float> P = make_params<float>(h, nullptr);
     launch_sample(P.seed_lo, P.seed_hi, (unsigned)iteration, h->cfg.K, h->cfg.T, h->cfg.k_offset, P.chol, eps_out,
-                  (hipStream_t)stream);
+                  (hipStream_t)stream, (unsigned)h->cfg.noise_stream);
     HIPCHECK(h, hipGetLastError());
     return MPPI_OK;
 }
@@ -839,6 +879,7 @@ extern "C" int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps
 extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *sampled_traj, void *stream) {
     int rc = check_ready(h, "mppi_rollout_viz");
     if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_rollout_viz");
     if (h->iter < 1) FAIL(h, MPPI_ERR_STATE, "mppi_rollout_viz before the first mppi_step");
     if (h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP)
         FAIL(h, MPPI_ERR_UNSUPPORTED, "visualisation rollouts are not built for the learned-dynamics model");
@@ -883,6 +924,7 @@ extern "C" int mppi_comm_close(mppi_handle *h) {
 
 extern "C" int mppi_comm_export(mppi_handle *h, int32_t nranks, void *handle_out) {
     if (!h || !handle_out) return MPPI_ERR_BAD_ARG;
+    SINGLE_AGENT_ONLY(h, "mppi_comm_export");
     if (nranks < 2 || nranks > XCHG_MAX_RANKS)
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_export: nranks must be 2..%d (got %d)", XCHG_MAX_RANKS, nranks);
     if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
@@ -983,9 +1025,14 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     while (done < target) {
         const long long todo = target - done;
         for (long long i = 0; i < todo; ++i) launch_slot<R>(h, P, F, s);
-        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, (size_t)h->B * h->res_bytes, hipMemcpyDeviceToHost, s));
         HIPCHECK(h, hipStreamSynchronize(s));
         HIPCHECK(h, hipGetLastError());
+        for (int a = 1; a < h->B; ++a) {  // an agent at the end of its path stops the batch like the single agent does
+            const StepResult *ra =
+                reinterpret_cast<const StepResult *>(reinterpret_cast<const char *>(h->h_res) + (size_t)a * h->res_bytes);
+            if (ra->status == STATUS_PATH_END) h->h_res->status = STATUS_PATH_END;
+        }
         if (h->h_res->status == STATUS_PATH_END || h->h_res->status == STATUS_EXCHANGE_FAILED) break;
         done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
         if (++guard > h->cfg.K + 8) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");

@@ -55,10 +55,12 @@ __host__ __device__ inline int record_len(int T, int elem_bytes) {
 }
 
 template <typename R> struct KParams {
-    int K, T, k_offset, n_exploit;
-    int n_ref, n_obs, window, model;
-    int accumulate, sequential, obstacle_model, clamp_rollout;
-    int wrap_stage, wrap_term, use_philox, traj_per_block;
+    int K, T, k_offset, noise_stream;  // noise_stream: fourth Philox counter word (of agent 0) -- kept in the first
+                                       // kernel-argument fetch: the draw is the first thing a wave does
+    int n_exploit, n_ref, n_obs, window;
+    int model, accumulate, sequential, obstacle_model;
+    int clamp_rollout, wrap_stage, wrap_term, use_philox;
+    int traj_per_block, slots;  // slots: several agents per launch, records per agent in the partials / heads buffers
     unsigned seed_lo, seed_hi;
     R dt, umax0, umax1, wheel_base;
     R beta, gamma, penalty, two_pi;
@@ -78,6 +80,8 @@ template <typename R> struct KParams {
     // call, mppi_differential_drive.py:96-99, was made by the host side of the ABI) instead of through *st
     int use_args, c_arg;
     double x0_arg[4];
+    // several agents per launch (blockIdx.y): agent a's u / S / pout / state / records / heads follow agent a-1's
+    int n_agents, pad5;
 };
 
 struct FinalizeParams {
@@ -108,6 +112,9 @@ struct FinalizeParams {
     long long x_timeout;     // 100 MHz ticks the wait may take before the iteration is abandoned
     char *const *x_peers;    // device array [x_nranks]: every rank's exchange buffer (own one included)
     int *x_err;              // sticky device flag: an exchange timed out, later slots return at once
+    // several agents per launch (blockIdx.y), see KParams
+    int slots, n_agents;
+    size_t res_stride;       // bytes between two agents' StepResult (+ returned u)
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights
@@ -146,7 +153,7 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f6
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
-                   float *eps_out, hipStream_t s);
+                   float *eps_out, hipStream_t s, unsigned stream_word = 0);
 template <typename R>
 void launch_viz(const KParams<R> &P, const R *u_before, const R *u_after_pre_shift, long long iter, float *opt,
                 float *smp, hipStream_t s);

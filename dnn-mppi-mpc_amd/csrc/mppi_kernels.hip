@@ -71,6 +71,7 @@ template <typename R>
 __global__ __launch_bounds__(64) void k_set_state(const R *ref, int n_ref, int window, int sequential, DevState *st,
                                                   double x0, double x1, double x2, double x3, int have_x) {
     const int lane = threadIdx.x;
+    st += blockIdx.x;  // one workgroup per agent (have_x: single agent only)
     if (have_x) {
         if (lane == 0) { st->x0[0] = x0; st->x0[1] = x1; st->x0[2] = x2; st->x0[3] = x3; }
     } else {
@@ -95,13 +96,14 @@ template <typename R, int MODEL> struct Rollout {
     const int n_chunk, lane_last;
     const RefPair<R> *win;  // the search window at c staged in LDS by the workgroup (or null)
     const R *obs;           // obstacle table: P.obs or its LDS copy
+    const int agent;        // several agents per launch (blockIdx.y): offsets into u / S / pout / state, noise stream
 
     __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_,
-                                       const RefPair<R> *win_, const R *obs_)
+                                       const RefPair<R> *win_, const R *obs_, int agent_ = 0)
         : P(P_), k(k_), lane(lane_), c(sv.c), iter((unsigned)sv.iter),
           exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)sv.x0[0]), cy((R)sv.x0[1]), cyaw((R)sv.x0[2]),
           cvel(MODEL == MODEL_RACE ? (R)sv.x0[3] : R(0)), p(sv.c), slow(false), s_acc(0), s_last(0),
-          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63), win(win_), obs(obs_) {}
+          n_chunk((P_.T + 63) >> 6), lane_last((P_.T - 1) & 63), win(win_), obs(obs_), agent(agent_) {}
 
     // this lane's noise for step t of sample k (S1, or the caller's tensor)
     __device__ __forceinline__ void load_eps(int ch, float &e0, float &e1) const {
@@ -110,7 +112,8 @@ template <typename R, int MODEL> struct Rollout {
         e1 = 0.f;
         if (t < P.T) {
             if (P.use_philox) {
-                px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1);
+                px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1,
+                           (unsigned)(P.noise_stream + agent));
             } else {
                 const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
                 e0 = e.x;
@@ -129,8 +132,9 @@ template <typename R, int MODEL> struct Rollout {
         STAMP(9);
         R u0 = 0, u1 = 0;
         if (act) {
-            u0 = P.u[2 * t];
-            u1 = P.u[2 * t + 1];
+            const R *u = P.u + (size_t)agent * 2 * P.T;
+            u0 = u[2 * t];
+            u1 = u[2 * t + 1];
         }
         R v0 = exploit ? u0 + (R)e0 : (R)e0, v1 = exploit ? u1 + (R)e1 : (R)e1;  // :116-119
         if (P.clamp_rollout) {                                                   // `_g` :285-289
@@ -245,9 +249,9 @@ template <typename R, int MODEL> struct Rollout {
         R total = wv::read_lane(s_last, lane_last);
         if (P.accumulate) total = (sizeof(R) == 4 ? s_acc : wv::reduce<wv::OpAdd>(s_acc)) + total;
         if (lane == 0) {
-            P.S[k] = total;
-            P.pout[k] = p;
-            if (P.sequential && p != c) atomicMin(&P.st->first_k, k);
+            P.S[(size_t)agent * P.K + k] = total;
+            P.pout[(size_t)agent * P.K + k] = p;
+            if (P.sequential && p != c) atomicMin(&(P.st + agent)->first_k, k);
         }
         return total;
     }
@@ -283,16 +287,19 @@ __global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const K
 // earlier speculation round) re-enter with their stored cost.
 constexpr int FUSED_WAVES = 16;
 
-template <typename R, int MODEL, int NCH>
+// MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
+// offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
+template <typename R, int MODEL, int NCH, bool MULTI>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevState *st_pre, const KParams<R> P,
                                                                     R *__restrict__ partials) {
+    const int agent = MULTI ? (int)blockIdx.y : 0;
     __shared__ R sh_S[FUSED_WAVES];
     __shared__ R sh_e[FUSED_WAVES];
     __shared__ R sh_acc[FUSED_WAVES][128 * NCH];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
     STAMP(0);
-    const DevState sv = load_state(P, st_pre);
+    const DevState sv = load_state(P, st_pre + agent);
     // (a workgroup whose samples are all final -- below k_start in a repair round -- rebuilds the same record from
     // the stored costs; an early exit here would keep the compiler from fetching the kernel arguments up front)
     const int k_start = sv.k_start;
@@ -311,14 +318,14 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs);
+        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
         if (k >= k_start) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
                 if (ch < r.n_chunk) r.chunk(ch, e0[ch], e1[ch]);
             S_k = r.finish();
         } else {
-            S_k = P.S[k];
+            S_k = P.S[(size_t)agent * P.K + k];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) r.load_eps(ch, e0[ch], e1[ch]);
         }
@@ -338,7 +345,8 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         sh_acc[wid][ch * 128 + 2 * lane + 1] = e * (R)e1[ch];
     }
     __syncthreads();
-    R *out = partials + (size_t)blockIdx.x * record_len(P.T, (int)sizeof(R));
+    const size_t slot = (size_t)agent * P.slots + blockIdx.x;  // this workgroup's record
+    R *out = partials + slot * record_len(P.T, (int)sizeof(R));
     for (int i = threadIdx.x; i < 2 * P.T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
         R s = 0;
 #pragma unroll
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
     }
     STAMP(4);
 }
@@ -373,9 +381,13 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 // 11 of 64) by one pass, ~40 % fewer instructions per sample.
 constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 
-template <typename R, int MODEL, int SPW>
+template <typename R, int MODEL, int SPW, bool MULTI>
 __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
+    const int agent = MULTI ? (int)blockIdx.y : 0;  // several agents per launch (see k_rollout_fused)
+    const R *__restrict__ u_ = P.u + (size_t)agent * 2 * P.T;
+    R *__restrict__ S_ = P.S + (size_t)agent * P.K;
+    int *__restrict__ pout_ = P.pout + (size_t)agent * P.K;
     constexpr int HL = 64 / SPW, SAMPLES = DUAL_WAVES * SPW;  // lanes per sample, samples per workgroup
     __shared__ R sh_S[SAMPLES];
     __shared__ R sh_e[SAMPLES];
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = SPW == 2 ? lane >> 5 : 0, l32 = lane & (HL - 1);
     const int seg0 = h * HL;  // first lane of this lane's sample
     STAMP(0);
-    const DevState sv = load_state(P, st_pre);
+    const DevState sv = load_state(P, st_pre + agent);
     const int k_start = sv.k_start;  // (no early exit for all-final workgroups, see k_rollout_fused)
     STAMP(1);
     const int k = (blockIdx.x * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     if (valid && a0) {
         if (P.use_philox) {
             unsigned r[4];
-            px::philox4x32_10((unsigned)(k + P.k_offset), (unsigned)l32, iter, 0u, P.seed_lo, P.seed_hi, r);
+            px::philox4x32_10((unsigned)(k + P.k_offset), (unsigned)l32, iter, (unsigned)(P.noise_stream + agent), P.seed_lo, P.seed_hi, r);
             px::box_muller(r[0], r[1], P.chol, e00, e01);
             px::box_muller(r[2], r[3], P.chol, e10, e11);
             if (!a1) { e10 = 0.f; e11 = 0.f; }
@@ -429,8 +441,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     if (__ballot(live) != 0ull) {  // at least one of the wave's two samples still needs its rollout
         const bool exploit = (k + P.k_offset) < P.n_exploit;
         R u00 = 0, u01 = 0, u10 = 0, u11 = 0;  // u<step><channel>
-        if (a0) { u00 = P.u[2 * t0]; u01 = P.u[2 * t0 + 1]; }
-        if (a1) { u10 = P.u[2 * t1]; u11 = P.u[2 * t1 + 1]; }
+        if (a0) { u00 = u_[2 * t0]; u01 = u_[2 * t0 + 1]; }
+        if (a1) { u10 = u_[2 * t1]; u11 = u_[2 * t1 + 1]; }
         R v00 = exploit ? u00 + (R)e00 : (R)e00, v01 = exploit ? u01 + (R)e01 : (R)e01;  // :116-119
         R v10 = exploit ? u10 + (R)e10 : (R)e10, v11 = exploit ? u11 + (R)e11 : (R)e11;
         if (P.clamp_rollout) {  // `_g` :285-289
@@ -561,12 +573,12 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         }
         S_k = total;
         if (l32 == 0 && live) {
-            P.S[k] = total;
-            P.pout[k] = p_half;
-            if (P.sequential && p_half != c) atomicMin(&P.st->first_k, k);
+            S_[k] = total;
+            pout_[k] = p_half;
+            if (P.sequential && p_half != c) atomicMin(&(P.st + agent)->first_k, k);
         }
     }
-    if (valid && !live) S_k = P.S[k];  // final from an earlier speculation round
+    if (valid && !live) S_k = S_[k];  // final from an earlier speculation round
     STAMP(2);
 
     // ---- the workgroup's softmin record over its samples (S5-S6) -----------------------------------------------
@@ -582,7 +594,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         dst[0] = e * (R)e00; dst[1] = e * (R)e01; dst[2] = e * (R)e10; dst[3] = e * (R)e11;
     }
     __syncthreads();
-    R *out = partials + (size_t)blockIdx.x * record_len(T, (int)sizeof(R));
+    const size_t slot = (size_t)agent * P.slots + blockIdx.x;  // this workgroup's record
+    R *out = partials + slot * record_len(T, (int)sizeof(R));
     for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
         R acc = 0;
 #pragma unroll
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
     }
     STAMP(4);
 }
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
             for (int i = wid; i < nk; i += nw) {
                 float e0, e1;
                 if (P.use_philox) {
-                    px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k0 + i + P.k_offset), t, P.chol, e0, e1);
+                    px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k0 + i + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
                 } else {
                     const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)(k0 + i) * P.T + t) * 2);
                     e0 = e.x;
@@ -999,7 +1012,8 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 // preloads into SGPRs (-amdgpu-kernarg-preload-count), so the first loads do not wait for the argument fetch.
 template <typename A, int MODE, int NT, int NWIN>
 __device__ __forceinline__ void finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
-                                              const void *u_pre, int T_pre, const FinalizeParams &F, char *smem) {
+                                              const void *u_pre, int T_pre, const FinalizeParams &F, char *smem,
+                                              int agent) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
     static_assert(MODE == 0 || NT == MERGE_THREADS, "the ABI / exchange variants are 256-thread kernels");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1007,11 +1021,16 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     const MergeLds<A, NT> L(smem, T, W);
     A *sh_w = L.w;  // weighted noise in the filter's padded layout: sample t of channel d at [2 (t + H) + d]
     A *sh_u = L.u;  // [2T] updated u
-    DevState *st_out = F.st_out;
-    StepResult *res = F.res;
+    // (`agent`: 0, or this workgroup's row of a batched launch -- every per-agent buffer is offset by it; the *_pre
+    // pointers arrive already offset)
+    DevState *st_out = F.st_out + agent;
+    StepResult *res = reinterpret_cast<StepResult *>(reinterpret_cast<char *>(F.res) + (size_t)agent * F.res_stride);
     double *res_u = reinterpret_cast<double *>(res + 1);
     const A *u_in = reinterpret_cast<const A *>(u_pre);
-    A *u_out = reinterpret_cast<A *>(F.u_out), *u_hist = reinterpret_cast<A *>(F.u_before);
+    A *u_out = reinterpret_cast<A *>(F.u_out) + (size_t)agent * 2 * T;
+    A *u_hist = reinterpret_cast<A *>(F.u_before) + (size_t)agent * 4 * T;
+    const int *pout = F.pout + (size_t)agent * F.K;
+    const void *partials = partials_pre;  // == F.partials + this agent's offset
     const A *ref = reinterpret_cast<const A *>(F.ref);
 
     STAMP(16);
@@ -1078,7 +1097,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
     if (F.sequential && fk != NO_TRIGGER) {
-        const int c_new = F.pout[fk];
+        const int c_new = pout[fk];
         if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
             nx.k_start = fk + 1;
             nx.c = c_new;
@@ -1124,11 +1143,11 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
     } else if (!XCHG) {
-        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
+        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
                                    eta, eta2, store_w);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
-        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(F.partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
+        merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
                                    eta, eta2, [&](int i, A v) { sh_u[i] = v; });
         const size_t slot_off = (size_t)(F.x_seq & 1) * xchg_slot_bytes(T, F.x_nranks);
         const size_t rec_off = slot_off + sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)F.x_rank * xchg_rec_len(T);
@@ -1253,7 +1272,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             res->rho = (double)rho; res->eta = (double)eta; res->ess = (double)(eta * eta / eta2);
             res->u0[0] = (double)u0a; res->u0[1] = (double)u0b;
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];
-            if (F.u0_trace) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
+            if (F.u0_trace && agent == 0) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
             res->iter = iter + 1;
         }
         if (F.plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
@@ -1284,25 +1303,34 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     STAMP(21);
 }
 
-template <typename A, int MODE, int NWIN>
+template <typename A, int MODE, int NWIN, bool MULTI>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
                                                             const DevState *st_pre, const void *u_pre, int T_pre,
                                                             const FinalizeParams F) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    finalize_body<A, MODE, MERGE_THREADS, NWIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem);
+    if (MULTI) {  // several agents per launch: workgroup row blockIdx.y finishes agent blockIdx.y
+        const int a = blockIdx.y;
+        const size_t rec = (size_t)a * F.slots * record_len(T_pre, (int)sizeof(A));
+        finalize_body<A, MODE, MERGE_THREADS, NWIN>(reinterpret_cast<const A *>(partials_pre) + rec,
+                                                    reinterpret_cast<const A *>(heads_pre) + (size_t)a * F.slots * 4,
+                                                    st_pre + a, reinterpret_cast<const A *>(u_pre) + (size_t)a * 2 * T_pre,
+                                                    T_pre, F, smem, a);
+    } else {
+        finalize_body<A, MODE, MERGE_THREADS, NWIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // S1 materialised (`_calc_epsilon`), and the visualisation rollouts (:144-159)
 // ------------------------------------------------------------------------------------------
 __global__ void k_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, float l00,
-                         float l10, float l11, float *__restrict__ eps) {
+                         float l10, float l11, float *__restrict__ eps, unsigned stream_word) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)K * T) return;
     const int k = (int)(i / T), t = (int)(i % T);
     const float chol[3] = {l00, l10, l11};
     float e0, e1;
-    px::sample(seed_lo, seed_hi, iter, (unsigned)(k + k_offset), t, chol, e0, e1);
+    px::sample(seed_lo, seed_hi, iter, (unsigned)(k + k_offset), t, chol, e0, e1, stream_word);
     reinterpret_cast<float2 *>(eps)[i] = make_float2(e0, e1);
 }
 
@@ -1335,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_viz(const KParams<R> P, const R *__rest
             } else {
                 float e0, e1;
                 if (P.use_philox) {
-                    px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(row + P.k_offset), tc, P.chol, e0, e1);
+                    px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(row + P.k_offset), tc, P.chol, e0, e1, (unsigned)P.noise_stream);
                 } else {
                     const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)row * P.T + tc) * 2);
                     e0 = e.x;
@@ -1382,9 +1410,10 @@ __global__ __launch_bounds__(256) void k_viz(const KParams<R> P, const R *__rest
 int reduce_blocks(int K, int traj_per_block) { return (K + traj_per_block - 1) / traj_per_block; }
 
 template <typename R> void launch_set_state(const KParams<R> &P, const double *x, hipStream_t s) {
+    const int agents = x ? 1 : (P.n_agents > 1 ? P.n_agents : 1);  // (an x0 passed by value: single agent only)
     const double z[4] = {0, 0, 0, 0};
     const double *v = x ? x : z;
-    hipLaunchKernelGGL(k_set_state<R>, dim3(1), dim3(64), 0, s, P.ref, P.n_ref, P.window, P.sequential, P.st, v[0],
+    hipLaunchKernelGGL(k_set_state<R>, dim3(agents), dim3(64), 0, s, P.ref, P.n_ref, P.window, P.sequential, P.st, v[0],
                        v[1], v[2], v[3], x ? 1 : 0);
 }
 
@@ -1417,16 +1446,20 @@ int fused_blocks(int K, int T) {
     return (K + per_block - 1) / per_block;
 }
 
-template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
-    const dim3 grid(fused_blocks(P.K, P.T));
+template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const KParams<R> &P, R *partials, hipStream_t s) {
+    const dim3 grid(fused_blocks(P.K, P.T), MULTI ? P.n_agents : 1);
     if (dual_layout(P.K, P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (pair_layout(P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (P.T <= 64)
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
     else
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+}
+template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
+    if (P.n_agents > 1) launch_fused_mm<R, MODEL, true>(P, partials, s);
+    else launch_fused_mm<R, MODEL, false>(P, partials, s);
 }
 
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s) {
@@ -1459,12 +1492,15 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_rec
                        (F.x_nranks > 1 ? sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(F.T) : 0);
     const DevState *st = F.st;
     const bool two = F.n_part > MERGE_MAX_RECORDS;  // (at most MERGE_MAX_WINDOWS * 256: the caller merges above that)
-#define MPPI_FIN(MODE, NWIN)                                                                                      \
-    hipLaunchKernelGGL((k_finalize<R, MODE, NWIN>), dim3(1), dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,  \
+    const bool multi = !abi_recs && F.x_nranks <= 1 && F.n_agents > 1;  // one workgroup per agent
+    const dim3 grid(1, multi ? F.n_agents : 1);
+#define MPPI_FIN(MODE, NWIN, MULTI)                                                                                    \
+    hipLaunchKernelGGL((k_finalize<R, MODE, NWIN, MULTI>), grid, dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,  \
                        (const void *)F.u, F.T, F)
-    if (abi_recs) MPPI_FIN(1, 1);
-    else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2); else MPPI_FIN(2, 1); }
-    else { if (two) MPPI_FIN(0, 2); else MPPI_FIN(0, 1); }
+    if (abi_recs) MPPI_FIN(1, 1, false);
+    else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2, false); else MPPI_FIN(2, 1, false); }
+    else if (multi) { if (two) MPPI_FIN(0, 2, true); else MPPI_FIN(0, 1, true); }
+    else { if (two) MPPI_FIN(0, 2, false); else MPPI_FIN(0, 1, false); }
 #undef MPPI_FIN
 }
 
@@ -1477,10 +1513,10 @@ template <typename R> void launch_weights(const KParams<R> &P, double rho, doubl
 }
 
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
-                   float *eps_out, hipStream_t s) {
+                   float *eps_out, hipStream_t s, unsigned stream_word) {
     const size_t n = (size_t)K * T;
     hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed_lo, seed_hi, iter, K, T,
-                       k_offset, chol[0], chol[1], chol[2], eps_out);
+                       k_offset, chol[0], chol[1], chol[2], eps_out, stream_word);
 }
 
 template <typename R>

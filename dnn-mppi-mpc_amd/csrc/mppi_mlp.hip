@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
         if (wid == 0) {
             float e0 = 0.f, e1 = 0.f;
             if (valid) {
-                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1);
+                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
                 else {
                     const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
                     e0 = e.x;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
         for (int t = 0; t < P.T; ++t) {  // second pass over this tile's noise rows (regenerated / re-read)
             float e0 = 0.f, e1 = 0.f;
             if (valid) {
-                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1);
+                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
                 else {
                     const float2 ee = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
                     e0 = ee.x;

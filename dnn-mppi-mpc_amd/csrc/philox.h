@@ -1,6 +1,6 @@
 // Counter-based control-noise sampler (stage S1).  Stands in for
 // np.random.multivariate_normal (controllers/mppi_differential_drive.py:273-283): Philox4x32-10
-// keyed by the seed, counter = (global sample k, t >> 1, iteration, stream); words (r0,r1)
+// keyed by the seed, counter = (global sample k, t >> 1, iteration, stream = agent / noise_stream); words (r0,r1)
 // serve even t and (r2,r3) odd t; Box-Muller; 2x2 Cholesky factor.  A sample depends only
 // on (seed, iteration, k_global, t), so K can be sharded over ranks without changing the
 // draw.  oracle/philox.py restates this in NumPy.
@@ -44,10 +44,11 @@ __device__ __forceinline__ void box_muller(unsigned ra, unsigned rb, const float
 }
 
 // eps[k_global, t, 0..1] ~ N(0, L L^T), chol = {L00, L10, L11}
+// (`stream`: the counter's fourth word -- 0, or the agent of a batched handle / mppi_config.noise_stream)
 __device__ __forceinline__ void sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned k_global, int t,
-                                       const float (&chol)[3], float &e0, float &e1) {
+                                       const float (&chol)[3], float &e0, float &e1, unsigned stream = 0u) {
     unsigned r[4];
-    philox4x32_10(k_global, (unsigned)t >> 1, iter, 0u, seed_lo, seed_hi, r);
+    philox4x32_10(k_global, (unsigned)t >> 1, iter, stream, seed_lo, seed_hi, r);
     const unsigned ra = (t & 1) ? r[2] : r[0], rb = (t & 1) ? r[3] : r[1];
     box_muller(ra, rb, chol, e0, e1);
 }

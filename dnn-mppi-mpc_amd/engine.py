@@ -45,6 +45,10 @@ class Engine:
         self.cfg = c
         self.K, self.T = int(c.K), int(c.T)
         self.nx = 4 if c.model == capi.MODEL_RACECAR else 3
+        # several independent problems in one handle: the state / control / cost accessors then carry a leading
+        # [n_agents] axis and run_closed_loop advances all of them in one launch per stage
+        self.n_agents = max(1, int(c.n_agents))
+        self._lead = (self.n_agents,) if self.n_agents > 1 else ()
         self._h = capi._H()
         rc = self.lib.mppi_create(C.byref(c), C.byref(self._h))
         if rc != capi.OK:
@@ -115,12 +119,12 @@ class Engine:
 
     def set_u_prev(self, u):
         u = np.ascontiguousarray(u, dtype=np.float64)
-        if u.shape != (self.T, 2):
-            raise ValueError(f"u_prev must be [{self.T}, 2]")
+        if u.shape != self._lead + (self.T, 2):
+            raise ValueError(f"u_prev must be {list(self._lead + (self.T, 2))}")
         self._ck(self.lib.mppi_set_u_prev(self._h, _dp(u)))
 
     def get_u_prev(self):
-        u = np.empty((self.T, 2))
+        u = np.empty(self._lead + (self.T, 2))
         self._ck(self.lib.mppi_get_u_prev(self._h, _dp(u)))
         return u
 
@@ -137,10 +141,12 @@ class Engine:
 
     def set_state(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != self._lead + (self.nx,):
+            raise ValueError(f"state must be {list(self._lead + (self.nx,))}")
         self._ck(self.lib.mppi_set_state(self._h, _dp(x)))
 
     def get_state(self):
-        x = np.empty(self.nx)
+        x = np.empty(self._lead + (self.nx,))
         self._ck(self.lib.mppi_get_state(self._h, _dp(x)))
         return x
 
@@ -222,7 +228,7 @@ class Engine:
         return u, u0, self.stats
 
     def costs(self):
-        S = np.empty(self.K)
+        S = np.empty(self._lead + (self.K,))
         self._ck(self.lib.mppi_get_costs(self._h, _dp(S)))
         return S
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 1
+#define MPPI_ABI_VERSION 2
 
 typedef enum {
     MPPI_OK = 0,
@@ -113,6 +113,17 @@ typedef struct {
     double vehicle_w, vehicle_l; /* race outline, 3.0 / 4.0 (mppi_race_car_obstacle.py:53-54) */
     double collision_penalty;    /* 1.0e10 */
     uint64_t seed;               /* Philox key for the on-device sampler */
+    /* Several independent MPPI problems ("agents") in one handle and one launch per stage:
+     * same parameters, reference path and obstacles, separate state, nominal controls, waypoint index and noise.
+     * 0/1 = one agent (every entry point).  > 1: needs MPPI_WAYPOINT_FROZEN, T <= 128, K <= 8192 and no sharding;
+     * mppi_set_state / mppi_get_state / mppi_set_u_prev / mppi_get_u_prev / mppi_get_costs then take [n_agents][...]
+     * arrays and mppi_run_closed_loop advances all agents (stats: agent 0; an agent that reaches the end of its path
+     * stops the call with MPPI_ERR_PATH_END); mppi_set_waypoint_idx / mppi_set_iteration apply to every agent; the
+     * host-in-the-loop and split steps, the visualisation rollouts and the exchange are single-agent. */
+    int32_t n_agents;
+    /* fourth word of the sampler's Philox counter (agent a of a batched handle draws with noise_stream + a, so a
+     * single-agent handle with noise_stream = a reproduces its noise) */
+    int32_t noise_stream;
 } mppi_config;
 
 /* per-iteration diagnostics (the reference only prints) */

@@ -74,9 +74,10 @@ def cholesky2(sigma):
     return np.array([[l00, 0.0], [l10, l11]])
 
 
-def sample_epsilon(sigma, seed: int, iteration: int, K: int, T: int, k_offset: int = 0) -> np.ndarray:
-    """eps[K, T, 2] as float32, distributed N(0, sigma)."""
-    z = standard_normal_pairs(seed, iteration, K, T, k_offset)
+def sample_epsilon(sigma, seed: int, iteration: int, K: int, T: int, k_offset: int = 0, stream: int = 0) -> np.ndarray:
+    """eps[K, T, 2] as float32, distributed N(0, sigma).  ``stream``: the counter's fourth word (mppi_config.noise_stream
+    + the agent of a batched handle)."""
+    z = standard_normal_pairs(seed, iteration, K, T, k_offset, stream)
     L = cholesky2(sigma).astype(np.float32).astype(np.float64)
     e0 = L[0, 0] * z[..., 0]
     e1 = L[1, 0] * z[..., 0] + L[1, 1] * z[..., 1]

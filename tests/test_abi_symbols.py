@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in mppi_hip.h but not exported"
     assert sorted(_capi.PROTOTYPES) == names  # the ctypes binding covers the header exactly
-    assert lib.mppi_abi_version() == 1
+    assert lib.mppi_abi_version() == 2
 
 
 def test_config_struct_matches_header_size():

@@ -454,3 +454,61 @@ def test_learned_dynamics_with_standard_scalers():
     u = c._calc_input_control(x0)[1]
     np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=1e-3, atol=1e-3)
     assert rmse(u, ref["u_returned"]) <= 1e-4
+
+
+@pytest.mark.parametrize("dual", ["0", "1"])
+@pytest.mark.parametrize("model", ["diff", "race"])
+def test_batched_agents_equal_separate_handles(monkeypatch, dual, model):
+    """`n_agents` problems in one handle (one launch per stage, agents as a grid dimension) against the same problems
+    in separate single-agent handles with `noise_stream` = the agent: identical closed loops."""
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    monkeypatch.setenv("MPPI_DUAL", dual)
+    B, K, n_it = 5, 300, 6
+    if model == "diff":
+        ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100)
+        base = dict(model=capi.MODEL_DIFFDRIVE, T=50, delta_t=0.1, u_max=[5.0, 3.14], param_exploration=0.05,
+                    param_lambda=1.0, param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01], stage_cost_weight=[5, 5, 10, 0],
+                    terminal_cost_weight=[5, 5, 10, 0], search_window=20, filter_window=10, clamp_rollout=1,
+                    waypoint_mode=capi.WAYPOINT_FROZEN, obstacle_model=capi.OBSTACLE_CIRCLE, safety_margin=0.8,
+                    collision_penalty=1e10, seed=99, precision=capi.PREC_F64)
+        obstacles = np.array([[2.0, -1.0, 0.4], [5.0, -2.5, 0.5]])
+        x0 = np.stack([[0.1 * a, -0.05 * a, 0.2 * a - 0.3] for a in range(B)])
+    else:
+        ref = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+        base = dict(model=capi.MODEL_RACECAR, T=40, delta_t=0.05, u_max=[0.523, 2.0], wheel_base=2.5, param_exploration=0.1,
+                    param_lambda=50.0, param_alpha=0.9, sigma=[0.5, 0.0, 0.0, 0.1], stage_cost_weight=[50.0, 50.0, 1.0, 20.0],
+                    terminal_cost_weight=[50.0, 50.0, 1.0, 20.0], beta_mode=capi.BETA_INV_LAMBDA, accumulate_stage_cost=1,
+                    waypoint_mode=capi.WAYPOINT_FROZEN, search_window=200, wrap_yaw_stage=1, wrap_yaw_terminal=1,
+                    clamp_rollout=1, clamp_u_after_update=1, filter_mode=capi.FILTER_RACECAR, filter_window=10,
+                    obstacle_model=capi.OBSTACLE_OUTLINE, safety_margin=1.5, vehicle_w=3.0, vehicle_l=4.0,
+                    collision_penalty=1e10, seed=7, precision=capi.PREC_F32)
+        obstacles = np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]])
+        x0 = np.stack([ref[2 + 3 * a].astype(np.float64) for a in range(B)])
+    batch = pkg.Engine(K=K, n_agents=B, **base)
+    batch.set_ref_path(ref)
+    batch.set_obstacles(obstacles)
+    batch.set_state(x0)
+    u_in = np.random.default_rng(3).normal(0, 0.1, (B, base["T"], 2))
+    batch.set_u_prev(u_in)
+    batch.run_closed_loop(n_it)
+    ub, xb, Sb = batch.get_u_prev(), batch.get_state(), batch.costs()
+    assert ub.shape == (B, base["T"], 2) and xb.shape == (B, batch.nx) and Sb.shape == (B, K)
+    tol = dict(rtol=1e-12, atol=1e-14) if model == "diff" else dict(rtol=1e-6, atol=1e-7)
+    for a in range(B):
+        one = pkg.Engine(K=K, noise_stream=a, **base)
+        one.set_ref_path(ref)
+        one.set_obstacles(obstacles)
+        one.set_state(x0[a])
+        one.set_u_prev(u_in[a])
+        one.run_closed_loop(n_it)
+        np.testing.assert_allclose(ub[a], one.get_u_prev(), **tol)
+        np.testing.assert_allclose(xb[a], one.get_state(), **tol)
+        np.testing.assert_allclose(Sb[a], one.costs(), **tol)
+    assert not np.allclose(ub[0], ub[1])  # the agents are different problems
+    with pytest.raises(pkg.MppiError) as ex:  # the host-in-the-loop step is single-agent
+        batch.step(x0[0])
+    assert ex.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(pkg.MppiError) as ex:  # the sequential waypoint index cannot be batched
+        pkg.Engine(K=K, n_agents=2, **dict(base, waypoint_mode=capi.WAYPOINT_SEQUENTIAL))
+    assert ex.value.code == capi.ERR_UNSUPPORTED
