@@ -109,14 +109,22 @@ class _ControllerBase:
         ok = all_ok(ok)
         if ok:
             handles = [None] * self._world
-            dist.all_gather_object(handles, handle, group=self._pg)
+            if cpu:
+                dist.all_gather_object(handles, handle, group=self._pg)
+            else:  # (the object collectives of the NCCL backend stage through the CURRENT device: make it this rank's)
+                with torch.cuda.device(eng.cfg.device):
+                    dist.all_gather_object(handles, handle, group=self._pg)
             try:
                 eng.comm_connect(self._rank, handles)
             except Exception:  # noqa: BLE001
                 ok = False
             ok = all_ok(ok)
         if ok:
-            dist.barrier(group=self._pg)
+            if cpu:
+                dist.barrier(group=self._pg)
+            else:
+                with torch.cuda.device(eng.cfg.device):
+                    dist.barrier(group=self._pg)
             try:
                 for _ in range(4):  # both slots, each reused once: records AND flags must arrive fresh
                     eng.comm_probe()
