@@ -123,34 +123,72 @@ template <typename R> __device__ __forceinline__ int window_len(int window, int 
 
 // collision indicator of one state (mppi_differential_drive_obs.py:301-313,
 // mppi_race_car_obstacle.py:241-274)
-// `obs`: P.obs, or the workgroup's LDS copy of it (stage_obstacles): after a kernel boundary the scalar cache is
-// cold, and 16 waves each walking the table with dependent scalar loads cost the launch microseconds
-constexpr int OBS_LDS_MAX = 64;
-template <typename R>
-__device__ __forceinline__ const R *stage_obstacles(R *sh_obs, const KParams<R> &P, int tid) {
-    if (P.obstacle_model == OBS_NONE || P.n_obs > OBS_LDS_MAX) return P.obs;
-    if (tid < 4 * P.n_obs) sh_obs[tid] = P.obs[tid];  // (the caller's barrier publishes it)
-    return sh_obs;
+// The obstacle table lives in registers: lane m holds circle m {centre, squared radius} (one vector load issued at
+// the top of the kernel, with all lanes active).  The loops below read one circle per iteration with v_readlane, so
+// there is no memory wait inside them; a table walked through a pointer costs a load round trip per circle -- and
+// the race car repeats the walk for each of its 8 outline points (config 4: 32 us per launch, 3/4 of it such waits).
+// Circles beyond the 64th come from P.obs directly.
+template <typename R> struct ObsLanes { R x, y, r2; };
+
+template <typename R> __device__ __forceinline__ ObsLanes<R> load_obstacles(const KParams<R> &P, int lane) {
+    ObsLanes<R> o{R(0), R(0), R(0)};
+    if (P.obstacle_model != OBS_NONE && lane < P.n_obs) {
+        const R *q = P.obs + 4 * lane;
+        o.x = q[0]; o.y = q[1]; o.r2 = q[2];
+    }
+    return o;
 }
 
-template <typename R>
-__device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, const R *__restrict__ obs) {
+// WIDE: the 8 outline points stay in registers and each circle is read once (the race-car kernels); otherwise the
+// points are visited one after the other, which keeps the diff-drive kernels at their register count
+template <bool WIDE, typename R>
+__device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, const ObsLanes<R> &tab) {
+    if (P.obstacle_model == OBS_NONE) return false;
     bool hit = false;
+    const int n_reg = P.n_obs < 64 ? P.n_obs : 64;
     if (P.obstacle_model == OBS_CIRCLE) {
-        for (int m = 0; m < P.n_obs; ++m) {
-            const R dx = x - obs[4 * m], dy = y - obs[4 * m + 1];
-            hit |= dx * dx + dy * dy < obs[4 * m + 2];
+        for (int m = 0; m < n_reg; ++m) {
+            const R dx = x - wv::read_lane(tab.x, m), dy = y - wv::read_lane(tab.y, m);
+            hit |= dx * dx + dy * dy < wv::read_lane(tab.r2, m);
         }
-    } else if (P.obstacle_model == OBS_OUTLINE) {
-        R sn, cs;
-        mf::sincos_(yaw, sn, cs);
+        for (int m = 64; m < P.n_obs; ++m) {
+            const R dx = x - P.obs[4 * m], dy = y - P.obs[4 * m + 1];
+            hit |= dx * dx + dy * dy < P.obs[4 * m + 2];
+        }
+        return hit;
+    }
+    // OBS_OUTLINE; the reference's 9th point repeats the 1st (mppi_race_car_obstacle.py:263-264)
+    R sn, cs;
+    mf::sincos_(yaw, sn, cs);
+    if (WIDE) {
+        R px[8], py[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {  // the reference's 9th point repeats the 1st (mppi_race_car_obstacle.py:263-264)
+        for (int q = 0; q < 8; ++q) {
+            px[q] = P.shape_x[q] * cs - P.shape_y[q] * sn + x;
+            py[q] = P.shape_x[q] * sn + P.shape_y[q] * cs + y;
+        }
+        auto circle = [&](R ox, R oy, R r2) {  // some outline point inside <=> the nearest one is
+            R dmin = R(INFINITY);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const R dx = px[q] - ox, dy = py[q] - oy;
+                dmin = fmin(dmin, dx * dx + dy * dy);
+            }
+            hit |= dmin < r2;
+        };
+        for (int m = 0; m < n_reg; ++m) circle(wv::read_lane(tab.x, m), wv::read_lane(tab.y, m), wv::read_lane(tab.r2, m));
+        for (int m = 64; m < P.n_obs; ++m) circle(P.obs[4 * m], P.obs[4 * m + 1], P.obs[4 * m + 2]);
+    } else {
+        for (int q = 0; q < 8; ++q) {
             const R px = P.shape_x[q] * cs - P.shape_y[q] * sn + x;
             const R py = P.shape_x[q] * sn + P.shape_y[q] * cs + y;
-            for (int m = 0; m < P.n_obs; ++m) {
-                const R dx = px - obs[4 * m], dy = py - obs[4 * m + 1];
-                hit |= dx * dx + dy * dy < obs[4 * m + 2];
+            for (int m = 0; m < n_reg; ++m) {
+                const R dx = px - wv::read_lane(tab.x, m), dy = py - wv::read_lane(tab.y, m);
+                hit |= dx * dx + dy * dy < wv::read_lane(tab.r2, m);
+            }
+            for (int m = 64; m < P.n_obs; ++m) {
+                const R dx = px - P.obs[4 * m], dy = py - P.obs[4 * m + 1];
+                hit |= dx * dx + dy * dy < P.obs[4 * m + 2];
             }
         }
     }

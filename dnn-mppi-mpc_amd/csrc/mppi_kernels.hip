@@ -95,11 +95,11 @@ template <typename R, int MODEL> struct Rollout {
     R s_acc, s_last;
     const int n_chunk, lane_last;
     const RefPair<R> *win;  // the search window at c staged in LDS by the workgroup (or null)
-    const R *obs;           // obstacle table: P.obs or its LDS copy
+    const ObsLanes<R> obs;  // obstacle table, one circle per lane
     const int agent;        // several agents per launch (blockIdx.y): offsets into u / S / pout / state, noise stream
 
     __device__ __forceinline__ Rollout(const KParams<R> &P_, const DevState &sv, int k_, int lane_,
-                                       const RefPair<R> *win_, const R *obs_, int agent_ = 0)
+                                       const RefPair<R> *win_, const ObsLanes<R> &obs_, int agent_ = 0)
         : P(P_), k(k_), lane(lane_), c(sv.c), iter((unsigned)sv.iter),
           exploit((k_ + P_.k_offset) < P_.n_exploit), cx((R)sv.x0[0]), cy((R)sv.x0[1]), cyaw((R)sv.x0[2]),
           cvel(MODEL == MODEL_RACE ? (R)sv.x0[3] : R(0)), p(sv.c), slow(false), s_acc(0), s_last(0),
@@ -209,7 +209,7 @@ template <typename R, int MODEL> struct Rollout {
         // ---- stage cost of every call (only the last one survives when !accumulate) ------
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
-            const bool hit = collided(P, x, y, yaw, obs);
+            const bool hit = collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs);
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, my_idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
@@ -224,7 +224,7 @@ template <typename R, int MODEL> struct Rollout {
                     // in f32 (ulp 1024) the order of the additions decides which tracking terms survive, so
                     // the f32 kernels add in the reference's order (s_acc is wave-uniform here).
                     const int n_act = min(64, P.T - ch * 64);
-                    for (int tt = 0; tt < n_act; ++tt) s_acc += wv::read_lane(stage, tt);
+                    s_acc = wv::ordered_sum(s_acc, stage, 0, n_act);
                 } else {
                     s_acc += act ? stage : R(0);
                 }
@@ -264,13 +264,10 @@ __global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const K
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
     const DevState sv = load_state(P, st_pre);
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
-    __shared__ R sh_obs[4 * OBS_LDS_MAX];
+    const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-    // (the obstacle table in LDS pays for the race car's 8 outline points x circles; the diff-drive kernels keep the
-    // scalar loads -- a generic pointer there costs registers and 0.2 us at config 2)
-    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;
     __syncthreads();
     if (k >= P.K || k < sv.k_start) return;
     Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs);
@@ -306,13 +303,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     STAMP(1);
     const bool valid = k < P.K;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
-    __shared__ R sh_obs[4 * OBS_LDS_MAX];
+    const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
-    const bool stage_obs = MODEL == MODEL_RACE && P.obstacle_model != OBS_NONE && P.n_obs <= OBS_LDS_MAX;
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;  // (see k_rollout)
-    if (use_win || stage_obs) __syncthreads();
+    if (use_win) __syncthreads();
     float e0[NCH], e1[NCH];
     R S_k = R(INFINITY);
 #pragma unroll
@@ -406,13 +401,11 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     const int T = P.T, t0 = 2 * l32, t1 = t0 + 1;
     const bool a0 = t0 < T, a1 = t1 < T;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
-    __shared__ R sh_obs[4 * OBS_LDS_MAX];
+    const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, c);
     const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
-    const bool stage_obs = MODEL == MODEL_RACE && P.obstacle_model != OBS_NONE && P.n_obs <= OBS_LDS_MAX;
     if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-    const R *obs = MODEL == MODEL_RACE ? stage_obstacles(sh_obs, P, (int)threadIdx.x) : P.obs;  // (see k_rollout)
-    if (use_win || stage_obs) __syncthreads();
+    if (use_win) __syncthreads();
 
     // ---- S1: this lane's noise for its two steps ---------------------------------------------------------
     float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel>
@@ -530,7 +523,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
 
         // ---- costs -----------------------------------------------------------------------------------------------
         auto stage_cost = [&](R x, R y, R yaw, R vel, int idx, R ua, R ub, R va, R vb, bool &hit) {
-            hit = collided(P, x, y, yaw, obs);
+            hit = collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs);
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
@@ -544,17 +537,17 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         if (P.accumulate) {
             bool hit0, hit1;
             const R st0 = stage_cost(px0, py0, yw0, vl0, idx0, u00, u01, v00, v01, hit0);
+            STAMP(12);
             const R st1 = stage_cost(px1, py1, yw1, vl1, idx1, u10, u11, v10, v11, hit1);
+            STAMP(13);
             const bool hit_l = sub_last ? hit1 : hit0;
             R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
             if (hit_l) term += P.penalty;
+            STAMP(14);
             R acc_a = 0, acc_b = 0;
             if (sizeof(R) == 4) {  // the reference's order of `S[k] += ...` (mppi_race_car.py:84), see Rollout::chunk
-                for (int t = 0; t < T; ++t) {
-                    const int src = t >> 1;
-                    acc_a += (t & 1) ? wv::read_lane(st1, src) : wv::read_lane(st0, src);
-                    if (SPW == 2) acc_b += (t & 1) ? wv::read_lane(st1, 32 + src) : wv::read_lane(st0, 32 + src);
-                }
+                acc_a = wv::ordered_sum2(acc_a, st0, st1, 0, T);
+                if (SPW == 2) acc_b = wv::ordered_sum2(acc_b, st0, st1, 32, T);
             } else {
                 const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
                 acc_a = wv::read_lane(part, HL - 1);

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
     const DevState sv = load_state(P, P.st);
+    const ObsLanes<float> obs = load_obstacles(P, lane);
     if (k0 + MLP_M <= sv.k_start) return;  // every sample of the tile is final: its record stands
     const bool valid = k < P.K, live = valid && k >= sv.k_start;
     const int c = sv.c;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
             }
             if (P.sequential) p = idx;
             if (P.accumulate || t == P.T - 1) {
-                const bool hit = collided(P, x, y, yaw, P.obs);
+                const bool hit = collided<false>(P, x, y, yaw, obs);
                 float st_c = tracking_cost<float, MODEL_DIFF>(P, P.ws, P.wrap_stage, idx, x, y, yaw, 0.f);
                 if (hit) st_c += P.penalty;
                 const float ctrl = (u0 * P.sinv[0] + u1 * P.sinv[2]) * v0 + (u0 * P.sinv[1] + u1 * P.sinv[3]) * v1;
