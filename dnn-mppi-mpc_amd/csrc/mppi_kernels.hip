@@ -376,25 +376,26 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 // 11 of 64) by one pass, ~40 % fewer instructions per sample.
 constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 
-template <typename R, int MODEL, int SPW, bool MULTI>
+// SEQ = samples each (half-)wave rolls out one after the other (1 or 2).  Past one workgroup per CU a second wave of
+// workgroups only repeats the prologue, the block reduction and the record: with SEQ = 2 the same waves do both
+// samples and the launch leaves half as many records for k_finalize to merge.
+template <typename R, int MODEL, int SPW, bool MULTI, int SEQ>
 __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
     const int agent = MULTI ? (int)blockIdx.y : 0;  // several agents per launch (see k_rollout_fused)
     const R *__restrict__ u_ = P.u + (size_t)agent * 2 * P.T;
     R *__restrict__ S_ = P.S + (size_t)agent * P.K;
     int *__restrict__ pout_ = P.pout + (size_t)agent * P.K;
-    constexpr int HL = 64 / SPW, SAMPLES = DUAL_WAVES * SPW;  // lanes per sample, samples per workgroup
+    // lanes per sample; samples in flight (one row of sh_acc each); samples per workgroup
+    constexpr int HL = 64 / SPW, ROWS = DUAL_WAVES * SPW, SAMPLES = ROWS * SEQ;
     __shared__ R sh_S[SAMPLES];
     __shared__ R sh_e[SAMPLES];
-    __shared__ __attribute__((aligned(16))) R sh_acc[SAMPLES][4 * HL];
+    __shared__ __attribute__((aligned(16))) R sh_acc[ROWS][4 * HL];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = SPW == 2 ? lane >> 5 : 0, l32 = lane & (HL - 1);
-    const int seg0 = h * HL;  // first lane of this lane's sample
     STAMP(0);
     const DevState sv = load_state(P, st_pre + agent);
     const int k_start = sv.k_start;  // (no early exit for all-final workgroups, see k_rollout_fused)
     STAMP(1);
-    const int k = (blockIdx.x * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
-    const bool valid = k < P.K, live = valid && k >= k_start;
     const int c = sv.c;
     const unsigned iter = (unsigned)sv.iter;
     const R *__restrict__ ref = P.ref;
@@ -407,8 +408,20 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
     if (use_win) __syncthreads();
 
+    float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel> of the sample in hand
+    R S_k = R(INFINITY);
+    bool valid = false;
+    float f00 = 0.f, f01 = 0.f, f10 = 0.f, f11 = 0.f;  // the same of the first pass (SEQ == 2)
+    R S_first = R(INFINITY);
+    bool valid_first = false;
+#pragma unroll
+    for (int pass = 0; pass < SEQ; ++pass) {
+    const int k = ((blockIdx.x * SEQ + pass) * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
+    valid = k < P.K;
+    const bool live = valid && k >= k_start;
+
     // ---- S1: this lane's noise for its two steps ---------------------------------------------------------
-    float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel>
+    e00 = 0.f; e01 = 0.f; e10 = 0.f; e11 = 0.f;
     STAMP(8);
     if (valid && a0) {
         if (P.use_philox) {
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         }
     }
     STAMP(9);
-    R S_k = R(INFINITY);
+    S_k = R(INFINITY);
     if (__ballot(live) != 0ull) {  // at least one of the wave's two samples still needs its rollout
         const bool exploit = (k + P.k_offset) < P.n_exploit;
         R u00 = 0, u01 = 0, u10 = 0, u11 = 0;  // u<step><channel>
@@ -572,19 +585,40 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         }
     }
     if (valid && !live) S_k = S_[k];  // final from an earlier speculation round
+    if (SEQ == 2 && pass == 0) {
+        f00 = e00; f01 = e01; f10 = e10; f11 = e11;
+        S_first = S_k;
+        valid_first = valid;
+    }
+    }  // pass
     STAMP(2);
 
     // ---- the workgroup's softmin record over its samples (S5-S6) -----------------------------------------------
-    const int sidx = wid * SPW + h;
-    if (l32 == 0) sh_S[sidx] = S_k;
+    const int sidx = wid * SPW + h;  // row of this (half-)wave; its first-pass sample sits ROWS further
+    if (l32 == 0) {
+        sh_S[sidx] = S_k;
+        if (SEQ == 2) sh_S[ROWS + sidx] = S_first;
+    }
     __syncthreads();
     STAMP(3);
-    const R rho = wv::read_lane(wv::scan_incl_seg<wv::OpMin, SPW>(l32 < SAMPLES ? sh_S[l32] : R(INFINITY)), HL - 1);
+    R s_min = R(INFINITY);
+#pragma unroll
+    for (int i = 0; i < SAMPLES; i += HL) s_min = fmin(s_min, i + l32 < SAMPLES ? sh_S[i + l32] : R(INFINITY));
+    const R rho = wv::read_lane(wv::scan_incl_seg<wv::OpMin, SPW>(s_min), HL - 1);
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
-    if (l32 == 0) sh_e[sidx] = e;
+    const R e_first = SEQ == 2 && valid_first ? mf::exp_(-P.beta * (S_first - rho)) : R(0);
+    if (l32 == 0) {
+        sh_e[sidx] = e;
+        if (SEQ == 2) sh_e[ROWS + sidx] = e_first;
+    }
     {
         R *dst = &sh_acc[sidx][4 * l32];
-        dst[0] = e * (R)e00; dst[1] = e * (R)e01; dst[2] = e * (R)e10; dst[3] = e * (R)e11;
+        if (SEQ == 2) {
+            dst[0] = e * (R)e00 + e_first * (R)f00; dst[1] = e * (R)e01 + e_first * (R)f01;
+            dst[2] = e * (R)e10 + e_first * (R)f10; dst[3] = e * (R)e11 + e_first * (R)f11;
+        } else {
+            dst[0] = e * (R)e00; dst[1] = e * (R)e01; dst[2] = e * (R)e10; dst[3] = e * (R)e11;
+        }
     }
     __syncthreads();
     const size_t slot = (size_t)agent * P.slots + blockIdx.x;  // this workgroup's record
@@ -592,7 +626,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t], :132-135
         R acc = 0;
 #pragma unroll
-        for (int q = 0; q < SAMPLES; ++q) acc += sh_acc[q][i];
+        for (int q = 0; q < ROWS; ++q) acc += sh_acc[q][i];
         out[4 + i] = acc;
     }
     if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
@@ -1434,17 +1468,35 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
+// k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per CU
+// (MPPI_SEQ=1/2 overrides for experiments)
+static int seq_passes(int K, int T) {
+    if (!dual_layout(K, T) && !pair_layout(T)) return 1;
+    if (const char *e = getenv("MPPI_SEQ")) return atoi(e) == 2 ? 2 : 1;
+    // more than one workgroup per CU, and at most 512 records after halving (what k_finalize merges directly).
+    // Beyond that the longer live ranges of the doubled body cost the rollout more than k_merge gains from fewer
+    // records: K = 65536 x T = 75 measured 158 us per iteration against 153 us with one pass.
+    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : DUAL_WAVES;
+    const int blocks = (K + per_block - 1) / per_block;
+    return blocks > 256 && blocks <= 1024 ? 2 : 1;
+}
 int fused_blocks(int K, int T) {
-    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES;  // (the pair layout: DUAL_WAVES = 16 too)
+    // (the pair layout: DUAL_WAVES = 16 = FUSED_WAVES samples per pass)
+    const int per_block = (dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES) * seq_passes(K, T);
     return (K + per_block - 1) / per_block;
 }
 
 template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const KParams<R> &P, R *partials, hipStream_t s) {
     const dim3 grid(fused_blocks(P.K, P.T), MULTI ? P.n_agents : 1);
-    if (dual_layout(P.K, P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+    const bool twice = seq_passes(P.K, P.T) == 2;
+    if (dual_layout(P.K, P.T) && twice)
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+    else if (dual_layout(P.K, P.T))
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+    else if (pair_layout(P.T) && twice)
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (pair_layout(P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
     else if (P.T <= 64)
         hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
     else

@@ -171,6 +171,24 @@ def test_long_horizon_racecar(monkeypatch, pair):
     assert rmse(u, ref["u_returned"]) <= 1e-4
 
 
+@pytest.mark.parametrize("case", ["diff-dual", "diff-pair", "race-dual", "race-pair"])
+def test_two_samples_per_wave_in_sequence(monkeypatch, case):
+    """MPPI_SEQ=2: k_rollout_dual's second pass (picked by itself only past one workgroup per CU, K >= 8192): ragged
+    sample counts where the second pass is partly or wholly empty, obstacles, the sequential waypoint index."""
+    monkeypatch.setenv("MPPI_SEQ", "2")
+    if case == "diff-dual":
+        for K, T, n_ref, obstacles in [(1, 10, 100, 0), (33, 25, 1, 2), (65, 64, 100, 1), (257, 50, 100, 3), (1000, 63, 7, 0)]:
+            test_ragged_diffdrive_shapes_match_oracle(monkeypatch, "1", K, T, n_ref, obstacles)
+    elif case == "diff-pair":
+        for K, T, obstacles in [(17, 128, 0), (33, 65, 0), (300, 77, 1)]:
+            test_long_horizon_layouts_match_oracle(monkeypatch, "1", K, T, obstacles)
+    elif case == "race-dual":
+        for K, T in [(19, 5), (65, 63), (130, 30)]:
+            test_ragged_racecar_shapes_match_oracle(monkeypatch, "1", K, T)
+    else:
+        test_long_horizon_racecar(monkeypatch, "1")
+
+
 def test_exchange_api_errors():
     """mppi_comm_*: call-order and mode errors are reported, the handle stays usable."""
     import dnn_mppi_mpc_amd as pkg
