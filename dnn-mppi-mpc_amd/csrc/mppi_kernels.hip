@@ -92,6 +92,7 @@ template <typename R, int MODEL> struct Rollout {
     R cx, cy, cyaw, cvel;  // state carried from chunk to chunk of 64 steps (wave-uniform)
     int p;                 // sequential mode: the threaded waypoint index
     bool slow;             // sequential mode: some call moved the index, evolve it call by call
+    bool hit_seen = false; // some step so far collided: the f32 cost sum must follow the reference's order
     R s_acc, s_last;
     const int n_chunk, lane_last;
     const RefPair<R> *win;  // the search window at c staged in LDS by the workgroup (or null)
@@ -222,9 +223,13 @@ template <typename R, int MODEL> struct Rollout {
                 if (sizeof(R) == 4) {
                     // `S[k] += ...` one step at a time (mppi_race_car.py:84): with 1e10 collision penalties
                     // in f32 (ulp 1024) the order of the additions decides which tracking terms survive, so
-                    // the f32 kernels add in the reference's order (s_acc is wave-uniform here).
-                    const int n_act = min(64, P.T - ch * 64);
-                    s_acc = wv::ordered_sum(s_acc, stage, 0, n_act);
+                    // a sample that has collided is added up in the reference's order (s_acc is wave-uniform
+                    // here).  Without a penalty in the sum the order moves the last ulps only (1e-7 relative,
+                    // like the rest of the f32 arithmetic) and a wave reduction does: ~15 instructions
+                    // instead of 2 per step, 15 % of the race-car launch at T = 75.
+                    hit_seen |= __ballot(act && hit) != 0ull;
+                    if (hit_seen) s_acc = wv::ordered_sum(s_acc, stage, 0, min(64, P.T - ch * 64));
+                    else s_acc += wv::reduce<wv::OpAdd>(act ? stage : R(0));
                 } else {
                     s_acc += act ? stage : R(0);
                 }
@@ -557,14 +562,12 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
             if (hit_l) term += P.penalty;
             STAMP(14);
-            R acc_a = 0, acc_b = 0;
-            if (sizeof(R) == 4) {  // the reference's order of `S[k] += ...` (mppi_race_car.py:84), see Rollout::chunk
-                acc_a = wv::ordered_sum2(acc_a, st0, st1, 0, T);
-                if (SPW == 2) acc_b = wv::ordered_sum2(acc_b, st0, st1, 32, T);
-            } else {
-                const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
-                acc_a = wv::read_lane(part, HL - 1);
-                acc_b = wv::read_lane(part, 63);
+            const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
+            R acc_a = wv::read_lane(part, HL - 1), acc_b = wv::read_lane(part, 63);
+            if (sizeof(R) == 4) {  // a sample that collided: the reference's order of `S[k] += ...`, see Rollout::chunk
+                const unsigned long long hm = __ballot((a0 && hit0) || (a1 && hit1));
+                if ((SPW == 2 ? hm & 0xffffffffull : hm) != 0ull) acc_a = wv::ordered_sum2(R(0), st0, st1, 0, T);
+                if (SPW == 2 && (hm >> 32) != 0ull) acc_b = wv::ordered_sum2(R(0), st0, st1, 32, T);
             }
             total = h ? acc_b + wv::read_lane(term, (SPW == 2 ? 32 : 0) + lane_last) : acc_a + wv::read_lane(term, lane_last);
         } else {  // `S[k] =`: only the last step's stage cost survives (:124)
