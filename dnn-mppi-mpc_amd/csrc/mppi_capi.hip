@@ -30,7 +30,8 @@ struct mppi_handle {
     std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
     StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
     long long seq = 0;
-    bool poll = true, idx_valid = true;
+    bool poll = true, idx_valid = true, by_args_ok = true;
+    int layout = 0;  // rollout_layout(K, T): which fused rollout kernel serves this handle
     MlpParams mlp;
     bool mlp_set = false;
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
@@ -145,7 +146,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (c.n_agents > 1) {
         if (c.n_agents > 4096) FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: n_agents %d > 4096", c.n_agents);
         if (c.waypoint_mode != MPPI_WAYPOINT_FROZEN || c.K_global != c.K || c.model == MPPI_MODEL_DIFFDRIVE_MLP ||
-            !fused_supported(c.T) || fused_blocks(c.K, c.T) > 512)
+            !fused_supported(c.T) || fused_blocks(c.K, c.T, rollout_layout(c.K, c.T)) > 512)
             FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
                  "several agents per handle need MPPI_WAYPOINT_FROZEN, an analytic model, T <= 128, at most 512 "
                  "rollout workgroups (K <= 8192) and no sharding");
@@ -182,7 +183,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->traj_per_block = tpb;
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
-    h->n_part = h->fused ? fused_blocks(c.K, c.T) : h->n_blocks;
+    h->layout = rollout_layout(c.K, c.T);
+    h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
     auto fail = [&](hipError_t e, const char *what) {
@@ -220,6 +222,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipHostGetDevicePointer((void **)&h->res_mapped, h->h_res, 0)) != hipSuccess)
         return fail(e, "hipHostGetDevicePointer(result)");
     h->poll = !getenv("MPPI_NO_POLL");
+    h->by_args_ok = !getenv("MPPI_NO_ARGS");
     if ((e = hipMemset(h->d_u, 0, B * r * 2 * c.T)) != hipSuccess) return fail(e, "hipMemset");    // u_prev = 0 (:82)
     if ((e = hipMemset(h->d_uhist, 0, B * r * 4 * c.T)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_S, 0, B * r * c.K)) != hipSuccess) return fail(e, "hipMemset");
@@ -468,6 +471,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.noise_stream = c.noise_stream;
     P.slots = h->slots;
     P.n_agents = h->B;
+    P.layout = h->layout;
     P.heads = (R *)h->d_heads;
     return P;
 }
@@ -684,7 +688,7 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
                      mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    const bool by_args = h->idx_valid && !getenv("MPPI_NO_ARGS");
+    const bool by_args = h->idx_valid && h->by_args_ok;
     if (by_args) {
         P.use_args = F.use_args = 1;
         P.c_arg = F.c_arg = host_x0_call(h, x0);

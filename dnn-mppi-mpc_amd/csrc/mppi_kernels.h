@@ -81,7 +81,7 @@ template <typename R> struct KParams {
     int use_args, c_arg;
     double x0_arg[4];
     // several agents per launch (blockIdx.y): agent a's u / S / pout / state / records / heads follow agent a-1's
-    int n_agents, pad5;
+    int n_agents, layout;   // layout: rollout_layout() of the handle (host side only)
 };
 
 struct FinalizeParams {
@@ -140,7 +140,11 @@ template <typename R> void launch_reduce(const KParams<R> &P, void *partials, in
 // rollout + cost + per-block softmin partial in one launch (T <= 128); fused_blocks(K) records
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s);
 bool fused_supported(int T);
-int fused_blocks(int K, int T);
+// Which fused rollout kernel serves (K, T): decided ONCE per handle (it reads the MPPI_DUAL / MPPI_PAIR / MPPI_SEQ
+// overrides) and carried in KParams::layout, so that a launch costs no environment lookups.
+enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
+int rollout_layout(int K, int T);
+int fused_blocks(int K, int T, int layout);  // workgroups = block records of one launch
 // merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
 // (`heads` / `out_heads`: the compact head arrays of the input / internal-layout output records)
 template <typename R>

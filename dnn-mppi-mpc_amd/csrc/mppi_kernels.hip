@@ -1471,39 +1471,40 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
-// k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per CU
-// (MPPI_SEQ=1/2 overrides for experiments)
-static int seq_passes(int K, int T) {
-    if (!dual_layout(K, T) && !pair_layout(T)) return 1;
-    if (const char *e = getenv("MPPI_SEQ")) return atoi(e) == 2 ? 2 : 1;
-    // more than one workgroup per CU, and at most 512 records after halving (what k_finalize merges directly).
-    // Beyond that the longer live ranges of the doubled body cost the rollout more than k_merge gains from fewer
-    // records: K = 65536 x T = 75 measured 158 us per iteration against 153 us with one pass.
-    const int per_block = dual_layout(K, T) ? DUAL_SAMPLES : DUAL_WAVES;
-    const int blocks = (K + per_block - 1) / per_block;
-    return blocks > 256 && blocks <= 1024 ? 2 : 1;
+int rollout_layout(int K, int T) {
+    const int kind = dual_layout(K, T) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
+    if (kind == LAYOUT_FUSED) return kind;
+    // k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per
+    // CU, and at most 512 records after halving (what k_finalize merges directly).  Beyond that the longer live
+    // ranges of the doubled body cost the rollout more than k_merge gains from fewer records: K = 65536 x T = 75
+    // measured 158 us per iteration against 153 us with one pass.  MPPI_SEQ=1/2 overrides for experiments.
+    const int blocks = fused_blocks(K, T, kind);
+    bool twice = blocks > 256 && blocks <= 1024;
+    if (const char *e = getenv("MPPI_SEQ")) twice = atoi(e) == 2;
+    return kind | (twice ? LAYOUT_TWICE : 0);
 }
-int fused_blocks(int K, int T) {
+int fused_blocks(int K, int T, int layout) {
     // (the pair layout: DUAL_WAVES = 16 = FUSED_WAVES samples per pass)
-    const int per_block = (dual_layout(K, T) ? DUAL_SAMPLES : FUSED_WAVES) * seq_passes(K, T);
+    const int per_block = ((layout & LAYOUT_KIND) == LAYOUT_DUAL ? DUAL_SAMPLES : FUSED_WAVES) * (layout & LAYOUT_TWICE ? 2 : 1);
     return (K + per_block - 1) / per_block;
 }
 
 template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const KParams<R> &P, R *partials, hipStream_t s) {
-    const dim3 grid(fused_blocks(P.K, P.T), MULTI ? P.n_agents : 1);
-    const bool twice = seq_passes(P.K, P.T) == 2;
-    if (dual_layout(P.K, P.T) && twice)
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
-    else if (dual_layout(P.K, P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
-    else if (pair_layout(P.T) && twice)
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
-    else if (pair_layout(P.T))
-        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
-    else if (P.T <= 64)
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
-    else
-        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+    const dim3 grid(fused_blocks(P.K, P.T, P.layout), MULTI ? P.n_agents : 1);
+    const bool twice = (P.layout & LAYOUT_TWICE) != 0;
+    switch (P.layout & LAYOUT_KIND) {
+    case LAYOUT_DUAL:
+        if (twice) hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        else hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 2, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        break;
+    case LAYOUT_PAIR:
+        if (twice) hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 2>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        else hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+        break;
+    default:
+        if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+    }
 }
 template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
     if (P.n_agents > 1) launch_fused_mm<R, MODEL, true>(P, partials, s);
