@@ -7,7 +7,14 @@ A "step" is one closed-loop MPPI iteration (sample -> rollout -> cost -> softmin
 filter -> shift, then the driver's plant advances the state) of BASELINE config 2: differential-drive,
 K=4096 samples x T=50 horizon, fp32, reference `__main__` parameters
 (controllers/mppi_differential_drive.py:400-410), synthetic straight-line path.  State, controls and the
-Philox-keyed noise live on the GPU; nothing crosses PCIe inside the timed region.  N > 1: one process
+Philox-keyed noise live on the GPU; nothing crosses PCIe inside the timed region.
+
+The timed steps are the iterations of the reference driver's own run, episodes back to back: the robot starts at the
+head of the 100-waypoint path with a fresh controller and the loop runs tSim = 1000 iterations
+(mppi_differential_drive.py:396) -- some 25 of them traverse the path (the waypoint index moves, the search window is
+up to 100 candidates long and the sequential index needs repair launches: ~70 us per iteration), the rest hold the
+goal (window of one candidate: ~9 us).  Timing only the hold phase would flatter the number, so every 1000 iterations
+the bench restarts the episode (three small uploads, inside the timed region); both phase latencies are reported too.  N > 1: one process
 per GPU (torch.distributed / RCCL), every rank evaluates K=4096 of K_global = N*4096 samples and one
 all-gather of {rho, eta, eta2, W[T,2]} per iteration merges the softmin (weak scaling).
 
@@ -30,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 K_SAMPLES, HORIZON = 4096, 50
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+EPISODE = 1000   # tSim of the reference driver (controllers/mppi_differential_drive.py:396)
+TRAVERSE = 25    # iterations the robot needs from the head of the path to its goal (measured; reported separately)
+X_INIT = np.zeros(3)  # init_x, :394
 
 
 def config2_kwargs(K=K_SAMPLES, T=HORIZON):
@@ -50,18 +60,21 @@ def cpu_baseline(budget_s=12.0):
     kw = config2_kwargs()
     o = c_oracle.DiffDriveC(**kw)
     pool = [philox.sample_epsilon(kw["sigma"], 1, i, K_SAMPLES, HORIZON) for i in range(4)]
-    state = np.zeros(3)
+    state = X_INIT.copy()
     o.iteration(state, pool[0])  # warm the caches
     o = c_oracle.DiffDriveC(**kw)
     n, spent = 0, 0.0
     while spent < budget_s:
+        if n % EPISODE == 0:  # the same run as the GPU path times: a new episode of the driver every tSim iterations
+            o = c_oracle.DiffDriveC(**kw)
+            state = X_INIT.copy()
         t0 = time.perf_counter()
         out = o.iteration(state, pool[n % len(pool)])
         spent += time.perf_counter() - t0
         state = mppi_oracle.diffdrive_plant_step(state, out["u0_returned"], kw["delta_t"])
         n += 1
     return {"value": K_SAMPLES * HORIZON * n / spent, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} closed-loop iterations of the same K=4096,T=50 workload in {spent:.1f} s "
+            "sample": f"the first {n} iterations of the same run (K=4096, T=50, episodes of {EPISODE}) in {spent:.1f} s "
                       "(oracle/mppi_oracle.c, scalar f64, noise pre-generated and excluded)",
             "ms_per_step": 1e3 * spent / n}
 
@@ -113,16 +126,34 @@ def main():
         ctrl = pkg.MPPIAlgorithms(**kw, precision="f32", device=local_rank, seed=2024, process_group=pg)
         eng = ctrl._engine
 
-        def run(n):
+        def loop(n):
             if not sharded:
                 eng.run_closed_loop(n, stream=stream)  # n complete iterations, one sync at the end
             else:
                 ctrl.run_closed_loop_sharded(n)
 
-        eng.set_state(np.zeros(3))
+        pos = [0]  # iterations done in the current episode
+
+        def restart():
+            ctrl.restart_episode(X_INIT)
+            pos[0] = 0
+
+        def run(n):  # n iterations of the driver's run, a new episode every EPISODE iterations
+            while n > 0:
+                if pos[0] == EPISODE:
+                    restart()
+                m = min(n, EPISODE - pos[0])
+                loop(m)
+                pos[0] += m
+                n -= m
+
+        restart()
         run(8)  # initialisation, not warm-up: the first launches load the code objects (milliseconds)
         barrier()
+        restart()
         run(max(1, args.warmup))
+        barrier()
+        restart()  # the timed region starts at the first iteration of an episode
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
@@ -134,12 +165,24 @@ def main():
             dt = float(t.item())
         idx_timed = int(eng.stats.idx_after)
 
+        def phase(n_skip, n):  # wall time per iteration of iterations [n_skip, n_skip + n) of an episode
+            restart()
+            if n_skip:
+                run(n_skip)
+            barrier()
+            t1 = time.perf_counter()
+            run(n)
+            barrier()
+            return (time.perf_counter() - t1) / n
+        phases = {"traverse": phase(0, TRAVERSE), "hold": phase(EPISODE // 2, EPISODE // 2)}
+
         # Kernel duration, measured live with HIP events on the launch stream over the same number of steps:
         # (a) the dominant kernel's launch-to-launch duration = growth of the iteration period when that
         #     (idempotent) kernel is launched twice per iteration -- two events around the whole region, so no
         #     per-launch event overhead enters; (b) per-launch event pairs with an empty-pair calibration.
         def timed_region(n):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            restart()
             barrier()
             e0.record(stream)
             run(n)
@@ -156,10 +199,10 @@ def main():
         barrier()
         kms = eng.last_kernel_ms()
         eng.enable_timing(False)
-        return ctrl, eng, dt, idx_timed, period_1x, period_2x, kms
+        return ctrl, eng, dt, idx_timed, period_1x, period_2x, kms, phases
 
     try:
-        ctrl, eng, dt, idx_timed, period_1x, period_2x, kms = measure()
+        ctrl, eng, dt, idx_timed, period_1x, period_2x, kms, phases = measure()
     except pkg.MppiError as ex:
         # the peer-to-peer exchange lost a rank (every rank then fails within its timeout): measure again with the
         # one collective per iteration instead
@@ -167,7 +210,7 @@ def main():
             raise
         os.environ["MPPI_EXCHANGE"] = "collective"
         barrier()
-        ctrl, eng, dt, idx_timed, period_1x, period_2x, kms = measure()
+        ctrl, eng, dt, idx_timed, period_1x, period_2x, kms, phases = measure()
     t_rollout = max(period_2x - period_1x, 1e-9)
 
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
@@ -220,10 +263,14 @@ def main():
                                       "reference __main__ parameters, closed loop with the driver's plant on the device",
                           "K_per_gpu": K_SAMPLES, "K_global": K_SAMPLES * world, "T": HORIZON,
                           "waypoint_mode": "frozen (K-sharded)" if sharded else "sequential (reference-exact)",
-                          "noise": "Philox4x32-10 in-kernel", "waypoint_idx_during_timing": idx_timed,
+                          "noise": "Philox4x32-10 in-kernel",
+                          "timed_iterations": "the reference driver's run from its initial state, restarted every %d "
+                                              "iterations (tSim): path traversal + holding the goal" % EPISODE,
                           "exchange": {"none": "none (one GPU)", "p2p": "peer-to-peer stores + flags inside k_finalize",
                                        "collective": "one all-gather per iteration (RCCL)"}[ctrl.exchange]},
                "iter_latency_us": 1e6 * dt / args.steps,
+               "phase_latency_us": {"traverse (first %d iterations of an episode)" % TRAVERSE: 1e6 * phases["traverse"],
+                                    "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

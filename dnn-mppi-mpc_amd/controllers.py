@@ -179,6 +179,17 @@ class _ControllerBase:
             self._engine.set_waypoint_idx(self._idx_host)
             self._idx_dev = self._idx_host
 
+    def restart_episode(self, x0):
+        """Back to the initial condition of the reference driver (a fresh controller and the robot at ``x0``,
+        mppi_differential_drive.py:393-441): nominal controls zero, waypoint index 0, and ``x0`` as the state of the
+        device-resident plant of ``run_closed_loop*``.  The noise counter keeps running (fresh noise every episode)."""
+        self._u_host[...] = 0.0
+        self._u_dev_copy[...] = 0.0
+        self._idx_host = self._idx_dev = 0
+        self._engine.set_u_prev(self._u_host)
+        self._engine.set_waypoint_idx(0)
+        self._engine.set_state(_arr(x0))
+
     # -- stage S1 ---------------------------------------------------------------------------------------
     def _calc_epsilon(self, sigma, size_sample, size_time_step, size_dim_u):
         """`_calc_epsilon` (mppi_differential_drive.py:273-283): the engine's Philox sampler for the

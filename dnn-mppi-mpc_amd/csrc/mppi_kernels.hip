@@ -93,6 +93,8 @@ template <typename R, int MODEL> struct Rollout {
     int p;                 // sequential mode: the threaded waypoint index
     bool slow;             // sequential mode: some call moved the index, evolve it call by call
     bool hit_seen = false; // some step so far collided: the f32 cost sum must follow the reference's order
+    bool doomed = false;   // sequential mode: a smaller sample of the workgroup moved the index too (see chunk)
+    int *sh_first = nullptr;  // LDS: smallest sample of the workgroup that moved the index so far (fused kernels)
     R s_acc, s_last;
     const int n_chunk, lane_last;
     const RefPair<R> *win;  // the search window at c staged in LDS by the workgroup (or null)
@@ -187,20 +189,60 @@ template <typename R, int MODEL> struct Rollout {
                 my_idx = nearest_in_window(ref, c, wlen, x, y);
             }
         } else {
+            // lane t's first minimum over the window at the incoming index: from the LDS copy of the window at c in
+            // one pass while the index still is c (one broadcast read per two candidates; walking the path with
+            // scalar loads cost every wave 2.8 us per 100 candidates), by the scalar walk below otherwise
+            int first_min = p;
+            bool have_first_min = false;
             if (!slow) {  // does any call move the index away from p?
                 const int wlen = window_len<R>(P.window, P.n_ref, p);
-                const R d0 = dist2(ref, p, x, y);
                 bool trig = false;
+                if (win != nullptr && p == c) {
+                    first_min = nearest_in_window_lds(win, c, wlen, x, y);
+                    trig = first_min != c;
+                    have_first_min = true;
+                } else {
+                    const R d0 = dist2(ref, p, x, y);
 #pragma unroll 4
-                for (int j = 1; j < wlen; ++j) trig |= dist2(ref, p + j, x, y) < d0;
+                    for (int j = 1; j < wlen; ++j) trig |= dist2(ref, p + j, x, y) < d0;
+                }
                 slow = __ballot(trig && act) != 0ull;
+                if (slow && sh_first) {
+                    // Only the FIRST sample that moves the index keeps its result this round (the later ones are
+                    // rolled out again from the index it leaves).  A wave that finds a smaller sample of its own
+                    // workgroup registered skips the threading below: while the robot travels every sample
+                    // moves the index, and with every wave threading its own a launch took 18 us instead of 7.
+                    int old = 0;
+                    if (lane == 0) old = atomicMin(sh_first, k);
+                    doomed = wv::read_lane(old, 0) < k;
+                }
             }
             my_idx = p;
-            if (slow) {  // rare: thread the index through this chunk's calls in order
+            if (slow && !doomed) {  // thread the index through this chunk's calls in order
+                // All calls at once first: lane t's first minimum over the window at the incoming index p0.  While
+                // that window reaches the path's end (or the index has not moved yet) the window of a later call
+                // [p, ..) is a suffix of it, so a first minimum at or beyond p IS that call's answer; only a
+                // minimum behind p needs the search proper.  (One dependent wave-wide search per call cost the
+                // wave that moves the index 14 us at config 2 -- the whole launch waited for it.)
+                const int p0 = p, w0 = window_len<R>(P.window, P.n_ref, p0);
+                const bool to_end = p0 + w0 >= P.n_ref;
+                if (!have_first_min) {
+                    R best = dist2(ref, p0, x, y);
+#pragma unroll 4
+                    for (int j = 1; j < w0; ++j) {
+                        const R d = dist2(ref, p0 + j, x, y);
+                        if (d < best) { best = d; first_min = p0 + j; }
+                    }
+                }
                 const int n_act = min(64, P.T - ch * 64);
                 for (int tt = 0; tt < n_act; ++tt) {
-                    const R xt = wv::read_lane(x, tt), yt = wv::read_lane(y, tt);
-                    p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                    const int a = wv::read_lane(first_min, tt);
+                    if (a >= p && (to_end || p == p0)) {
+                        p = a;
+                    } else {
+                        const R xt = wv::read_lane(x, tt), yt = wv::read_lane(y, tt);
+                        p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                    }
                     if (lane == tt) my_idx = p;
                 }
             }
@@ -237,7 +279,7 @@ template <typename R, int MODEL> struct Rollout {
             if (last_chunk) {
                 // terminal call: same state; the sequential index takes one more step (:244)
                 int idx_term = my_idx;
-                if (P.sequential && slow) {
+                if (P.sequential && slow && !doomed) {
                     const R xt = wv::read_lane(x, lane_last), yt = wv::read_lane(y, lane_last);
                     p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                     idx_term = p;
@@ -250,16 +292,20 @@ template <typename R, int MODEL> struct Rollout {
     }
 
     // S[k] once every chunk has run; also publishes the index this sample leaves behind
-    __device__ __forceinline__ R finish() {
+    // `publish`: register this sample in first_k if it moved the index.  The fused kernels pass false and register
+    // the smallest such sample of the WORKGROUP instead (publish_first_mover): while the robot travels every sample
+    // moves the index, and 4096 atomics on one address kept a launch busy for ~15 us after its last wave.
+    __device__ __forceinline__ R finish(bool publish = true) {
         R total = wv::read_lane(s_last, lane_last);
         if (P.accumulate) total = (sizeof(R) == 4 ? s_acc : wv::reduce<wv::OpAdd>(s_acc)) + total;
         if (lane == 0) {
             P.S[(size_t)agent * P.K + k] = total;
             P.pout[(size_t)agent * P.K + k] = p;
-            if (P.sequential && p != c) atomicMin(&(P.st + agent)->first_k, k);
+            if (publish && moved()) atomicMin(&(P.st + agent)->first_k, k);
         }
         return total;
     }
+    __device__ __forceinline__ bool moved() const { return P.sequential && p != c; }
 };
 
 // Any horizon: S[k] only (the softmin partials come from k_reduce).
@@ -271,7 +317,7 @@ __global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const K
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
-    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    const bool use_win = wlen0 <= WINDOW_LDS_MAX;  // (both waypoint modes search the window at c first)
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
     __syncthreads();
     if (k >= P.K || k < sv.k_start) return;
@@ -288,6 +334,14 @@ __global__ __launch_bounds__(256) void k_rollout(const DevState *st_pre, const K
 // fused into S2-S4); the block's waves meet once in LDS.  Samples below k_start (already final in an
 // earlier speculation round) re-enter with their stored cost.
 constexpr int FUSED_WAVES = 16;
+
+// one atomic per workgroup: the smallest of its samples that moved the waypoint index, if any (one thread calls)
+template <int N> __device__ __forceinline__ void publish_first_mover(const int *sh_mover, int *first_k) {
+    int m = NO_TRIGGER;
+#pragma unroll
+    for (int q = 0; q < N; ++q) m = min(m, sh_mover[q]);
+    if (m != NO_TRIGGER) atomicMin(first_k, m);
+}
 
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
@@ -310,20 +364,30 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
-    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    // Both waypoint modes search the window at c first.  A sequential-mode window of ONE candidate (the robot holds
+    // the end of the path) leaves nothing to search or to move: no staging and no barrier behind its loads then
+    // (0.7 us per launch at config 2).
+    const bool seq_search = P.sequential && wlen0 > 1;
+    const bool use_win = wlen0 <= WINDOW_LDS_MAX && (seq_search || !P.sequential);
+    __shared__ int sh_mover[FUSED_WAVES];
+    __shared__ int sh_first;
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-    if (use_win) __syncthreads();
+    if (seq_search && threadIdx.x == 0) sh_first = NO_TRIGGER;
+    if (use_win || seq_search) __syncthreads();
     float e0[NCH], e1[NCH];
     R S_k = R(INFINITY);
+    int mover = NO_TRIGGER;  // this wave's sample if it moved the waypoint index (sequential mode)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
         Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
+        r.sh_first = seq_search ? &sh_first : nullptr;
         if (k >= k_start) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
                 if (ch < r.n_chunk) r.chunk(ch, e0[ch], e1[ch]);
-            S_k = r.finish();
+            S_k = r.finish(false);
+            if (r.moved()) mover = k;
         } else {
             S_k = P.S[(size_t)agent * P.K + k];
 #pragma unroll
@@ -331,7 +395,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         }
     }
     STAMP(2);
-    if (lane == 0) sh_S[wid] = S_k;
+    if (lane == 0) {
+        sh_S[wid] = S_k;
+        if (seq_search) sh_mover[wid] = mover;
+    }
     __syncthreads();
     STAMP(3);
     R rho = sh_S[0];
@@ -365,6 +432,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         out[1] = eta;
         out[2] = eta2;
         *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+        if (seq_search) publish_first_mover<FUSED_WAVES>(sh_mover, &(P.st + agent)->first_k);
     }
     STAMP(4);
 }
@@ -409,9 +477,12 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, c);
-    const bool use_win = !P.sequential && wlen0 <= WINDOW_LDS_MAX;
+    const bool seq_search = P.sequential && wlen0 > 1;  // (see k_rollout_fused)
+    const bool use_win = wlen0 <= WINDOW_LDS_MAX && (seq_search || !P.sequential);
+    __shared__ int sh_first;  // smallest sample of the workgroup that moved the index so far (see Rollout::chunk)
     if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
-    if (use_win) __syncthreads();
+    if (seq_search && threadIdx.x == 0) sh_first = NO_TRIGGER;
+    if (use_win || seq_search) __syncthreads();
 
     float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;  // e<step><channel> of the sample in hand
     R S_k = R(INFINITY);
@@ -419,6 +490,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     float f00 = 0.f, f01 = 0.f, f10 = 0.f, f11 = 0.f;  // the same of the first pass (SEQ == 2)
     R S_first = R(INFINITY);
     bool valid_first = false;
+    int mover = NO_TRIGGER;  // the smaller of this half-wave's samples that moved the waypoint index (sequential mode)
+    __shared__ int sh_mover[ROWS];
 #pragma unroll
     for (int pass = 0; pass < SEQ; ++pass) {
     const int k = ((blockIdx.x * SEQ + pass) * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
@@ -513,23 +586,53 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         } else {
             const int wlen = window_len<R>(P.window, P.n_ref, c);
             const R d00 = dist2(ref, c, px0, py0), d01 = dist2(ref, c, px1, py1);
+            int fm0 = c, fm1 = c;  // first minimum of each of the lane's two calls over the window at c (see Rollout::chunk)
             bool trig = false;
+            if (use_win) {
+                fm0 = nearest_in_window_lds(sh_win, c, wlen, px0, py0);
+                fm1 = nearest_in_window_lds(sh_win, c, wlen, px1, py1);
+                trig = (a0 && fm0 != c) || (a1 && fm1 != c);
+            } else {
 #pragma unroll 4
-            for (int j = 1; j < wlen; ++j)
-                trig |= (a0 && dist2(ref, c + j, px0, py0) < d00) || (a1 && dist2(ref, c + j, px1, py1) < d01);
-            const unsigned long long m = __ballot(trig);
+                for (int j = 1; j < wlen; ++j)
+                    trig |= (a0 && dist2(ref, c + j, px0, py0) < d00) || (a1 && dist2(ref, c + j, px1, py1) < d01);
+            }
+            unsigned long long m = __ballot(trig && live);
+            for (int hh = 0; hh < SPW; ++hh) {  // a smaller sample of the workgroup moved the index too: skip (see Rollout::chunk)
+                const unsigned long long half = SPW == 2 ? 0xffffffffull << (32 * hh) : ~0ull;
+                if ((m & half) == 0ull) continue;
+                const int k_hh = k - h + hh;
+                int old = 0;
+                if (lane == 0) old = atomicMin(&sh_first, k_hh);
+                if (wv::read_lane(old, 0) < k_hh) m &= ~half;
+            }
             int p_a = c, p_b = c, term_a = c, term_b = c;
-            for (int hh = 0; hh < SPW; ++hh) {  // rare: thread the index through that sample's calls in order
+            const bool to_end = c + wlen >= P.n_ref;
+            if (m != 0ull && !use_win) {
+                R b0 = d00, b1 = d01;
+#pragma unroll 4
+                for (int j = 1; j < wlen; ++j) {
+                    const R e0 = dist2(ref, c + j, px0, py0), e1 = dist2(ref, c + j, px1, py1);
+                    if (e0 < b0) { b0 = e0; fm0 = c + j; }
+                    if (e1 < b1) { b1 = e1; fm1 = c + j; }
+                }
+            }
+            for (int hh = 0; hh < SPW; ++hh) {  // thread the index through that sample's calls in order
                 if ((SPW == 2 ? ((hh ? (m >> 32) : m) & 0xffffffffull) : m) == 0ull) continue;
                 int p = c;
                 for (int t = 0; t < T; ++t) {
                     const int src = hh * HL + (t >> 1);
+                    const int a = (t & 1) ? wv::read_lane(fm1, src) : wv::read_lane(fm0, src);
+                    const bool direct = a >= p && (to_end || p == c);
                     const R xt = (t & 1) ? wv::read_lane(px1, src) : wv::read_lane(px0, src);
                     const R yt = (t & 1) ? wv::read_lane(py1, src) : wv::read_lane(py0, src);
-                    p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                    if (direct) p = a;
+                    else p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                     if (lane == src) { if (t & 1) idx1 = p; else idx0 = p; }
-                    if (t == t_last) {  // the terminal call moves the index once more (:244)
-                        p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
+                    if (t == t_last) {  // the terminal call searches once more from the same state (:244)
+                        // (from a direct answer a the suffix [a, ..) has its first minimum at a itself)
+                        if (!(direct && (to_end || p == c)))
+                            p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                         if (hh) { term_b = p; p_b = p; } else { term_a = p; p_a = p; }
                     }
                 }
@@ -584,8 +687,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         if (l32 == 0 && live) {
             S_[k] = total;
             pout_[k] = p_half;
-            if (P.sequential && p_half != c) atomicMin(&(P.st + agent)->first_k, k);
         }
+        if (live && P.sequential && p_half != c) mover = min(mover, k);  // (uniform within the half; SEQ passes ascend)
     }
     if (valid && !live) S_k = S_[k];  // final from an earlier speculation round
     if (SEQ == 2 && pass == 0) {
@@ -601,6 +704,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     if (l32 == 0) {
         sh_S[sidx] = S_k;
         if (SEQ == 2) sh_S[ROWS + sidx] = S_first;
+        if (seq_search) sh_mover[sidx] = mover;
     }
     __syncthreads();
     STAMP(3);
@@ -644,6 +748,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         out[1] = eta;
         out[2] = eta2;
         *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+        if (seq_search) publish_first_mover<ROWS>(sh_mover, &(P.st + agent)->first_k);
     }
     STAMP(4);
 }

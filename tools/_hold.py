@@ -1,0 +1,14 @@
+import sys, os, time, numpy as np
+sys.path.insert(0, os.getcwd())
+import torch
+import dnn_mppi_mpc_amd as pkg
+from bench import config2_kwargs
+ctrl = pkg.MPPIAlgorithms(**config2_kwargs(), precision="f32", seed=1)
+eng = ctrl._engine
+eng.set_state(np.zeros(3)); eng.run_closed_loop(300); torch.cuda.synchronize()
+res = []
+for rep in range(6):
+    t0 = time.perf_counter(); eng.run_closed_loop(3000); torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 3000 * 1e6)
+eng.set_u_prev(np.zeros((50, 2))); eng.set_waypoint_idx(0); eng.set_state(np.zeros(3)); torch.cuda.synchronize()
+t0 = time.perf_counter(); eng.run_closed_loop(25); torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / 25 * 1e6
+print(os.environ.get("MPPI_LIB", "new")[-12:], "hold min %.2f med %.2f" % (min(res), sorted(res)[3]), "traverse %.1f" % tr)

@@ -13,7 +13,7 @@ import torch  # noqa: E402,F401
 import dnn_mppi_mpc_amd as pkg  # noqa: E402
 from dnn_mppi_mpc_amd import _capi  # noqa: E402
 
-_capi.LIB_PATH = os.path.join(ROOT, "dnn-mppi-mpc_amd", "lib", "libmppi_hip_stamps.so")
+_capi.LIB_PATH = os.environ.get("MPPI_STAMPS_LIB") or os.path.join(ROOT, "dnn-mppi-mpc_amd", "lib", "libmppi_hip_stamps.so")
 from bench import config2_kwargs  # noqa: E402
 
 which = sys.argv[2] if len(sys.argv) > 2 else "2"   # "2" (bench.py's workload) or "4s" (race car, K=8192, T=75)
