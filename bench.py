@@ -253,8 +253,15 @@ def main():
                 "note": "kernel_us = launch-to-launch duration of k_rollout_fused on its stream (period with the kernel "
                         "launched twice per iteration minus the normal period, HIP events around the whole region); "
                         "event_pair_us = per-launch event pairs minus the empty-pair calibration (excludes dispatch). "
+                        "Averaged over whole episodes, i.e. including the repair launches of the traversal phase. "
                         "Noise is drawn in-kernel (Philox) and never touches HBM, so PMC traffic is far below the "
-                        "algorithmic bytes: the launch is VALU-issue/latency bound, not HBM bound"}
+                        "algorithmic bytes: the launch is bound by VALU issue, not by HBM (valu_issue)"}
+        valu_file = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+        if os.path.exists(valu_file):  # PMC instruction counters of this same command (profiles/README.md)
+            v = next(x for k, x in json.load(open(valu_file)).items() if k.startswith("config 2"))
+            roof["valu_issue"] = {"valu_instructions_per_wave": v["per_wave"]["VALU"], "waves_per_simd": v["waves_per_simd"],
+                                  "issue_us": v["valu_issue_us"], "of_event_pair_rollout_us": 1e3 * kms["rollout"],
+                                  "source": "profiles/r01_pmc_valu.json (hold-phase launches)"}
         out = {"metric": "trajectory-steps/sec (KxT/iter_time), diff-drive K=4096 T=50", "value": units * args.steps / dt,
                "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -321,6 +321,29 @@ def test_device_closed_loop_matches_host_loop():
     assert st.iteration == n
 
 
+def test_restart_episode_reproduces_a_fresh_controller():
+    """`restart_episode` (what bench.py calls every tSim iterations): nominal controls, waypoint index and plant
+    state go back to the driver's initial condition -- with the noise counter rewound too, the run that follows is
+    the fresh controller's run bit for bit, traversal of the path (index moves, repair launches) included."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(1024, 30)
+    n = 40
+    fresh = pkg.MPPIAlgorithms(**kw, precision="f32", seed=9)
+    fresh._engine.set_state(np.zeros(3))
+    tr_a, st_a = fresh._engine.run_closed_loop(n, trace=True)
+    used = pkg.MPPIAlgorithms(**kw, precision="f32", seed=9)
+    used._engine.set_state(np.array([0.3, -0.2, 0.1]))
+    used._engine.run_closed_loop(60)
+    assert used._engine.get_waypoint_idx() > 0 and np.abs(used._engine.get_u_prev()).max() > 0
+    used.restart_episode(np.zeros(3))
+    assert used.prev_way_point_idx == 0 and not used.u_prev.any()
+    used._engine.set_iteration(0)
+    tr_b, st_b = used._engine.run_closed_loop(n, trace=True)
+    np.testing.assert_array_equal(tr_a, tr_b)
+    np.testing.assert_array_equal(fresh._engine.get_state(), used._engine.get_state())
+    assert st_a.idx_after == st_b.idx_after and st_a.idx_after > 0
+
+
 def test_fused_and_unfused_paths_agree(monkeypatch):
     """T <= 128 runs rollout+softmin partial in one launch; MPPI_FORCE_UNFUSED=1 selects the separate
     k_rollout / k_reduce launches (the only path for longer horizons).  Same iteration either way."""
