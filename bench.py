@@ -13,8 +13,10 @@ The timed steps are the iterations of the reference driver's own run, episodes b
 head of the 100-waypoint path with a fresh controller and the loop runs tSim = 1000 iterations
 (mppi_differential_drive.py:396) -- some 25 of them traverse the path (the waypoint index moves, the search window is
 up to 100 candidates long and the sequential index needs repair launches: ~70 us per iteration), the rest hold the
-goal (window of one candidate: ~9 us).  Timing only the hold phase would flatter the number, so every 1000 iterations
-the bench restarts the episode (three small uploads, inside the timed region); both phase latencies are reported too.  N > 1: one process
+goal (window of one candidate: ~9 us).  A run that never leaves the hold phase would flatter the number, so the bench
+restarts the episode every 1000 iterations of its run (initialisation + warm-up + timed steps; three small uploads,
+timed when they fall into the timed region) -- with the default 2000 steps two traversals are inside the timed region --
+and reports both phase latencies as well.  N > 1: one process
 per GPU (torch.distributed / RCCL), every rank evaluates K=4096 of K_global = N*4096 samples and one
 all-gather of {rho, eta, eta2, W[T,2]} per iteration merges the softmin (weak scaling).
 
@@ -147,13 +149,12 @@ def main():
                 pos[0] += m
                 n -= m
 
+        # one continuous run of the driver's loop: initialisation, warm-up, then the timed steps (BASELINE.md section 3:
+        # closed-loop iterations after the warm-ups); a new episode begins every EPISODE iterations of that run
         restart()
         run(8)  # initialisation, not warm-up: the first launches load the code objects (milliseconds)
         barrier()
-        restart()
         run(max(1, args.warmup))
-        barrier()
-        restart()  # the timed region starts at the first iteration of an episode
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
@@ -182,7 +183,6 @@ def main():
         #     per-launch event overhead enters; (b) per-launch event pairs with an empty-pair calibration.
         def timed_region(n):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            restart()
             barrier()
             e0.record(stream)
             run(n)
@@ -271,8 +271,10 @@ def main():
                           "K_per_gpu": K_SAMPLES, "K_global": K_SAMPLES * world, "T": HORIZON,
                           "waypoint_mode": "frozen (K-sharded)" if sharded else "sequential (reference-exact)",
                           "noise": "Philox4x32-10 in-kernel",
-                          "timed_iterations": "the reference driver's run from its initial state, restarted every %d "
-                                              "iterations (tSim): path traversal + holding the goal" % EPISODE,
+                          "timed_iterations": "closed-loop iterations %d..%d of the reference driver's run, which restarts "
+                                              "from its initial state every %d iterations (tSim): path traversal + "
+                                              "holding the goal" % (8 + max(1, args.warmup), 8 + max(1, args.warmup) + args.steps,
+                                                                    EPISODE),
                           "exchange": {"none": "none (one GPU)", "p2p": "peer-to-peer stores + flags inside k_finalize",
                                        "collective": "one all-gather per iteration (RCCL)"}[ctrl.exchange]},
                "iter_latency_us": 1e6 * dt / args.steps,
