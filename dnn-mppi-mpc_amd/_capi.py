@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
 LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.so")  # MPPI_LIB: A/B a diagnostic build
 
 # enums of mppi_hip.h
@@ -116,7 +117,7 @@ def load_library(path: str | None = None):
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != 2:
+    if lib.mppi_abi_version() != ABI_VERSION:
         raise MppiError(ERR_BAD_ARG, "ABI version mismatch between _capi.py and libmppi_hip.so")
     if path is None:
         _lib = lib

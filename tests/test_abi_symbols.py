@@ -31,7 +31,19 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in mppi_hip.h but not exported"
     assert sorted(_capi.PROTOTYPES) == names  # the ctypes binding covers the header exactly
-    assert lib.mppi_abi_version() == 2
+    header = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
+    declared = int(re.search(r"#define\s+MPPI_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.mppi_abi_version() == declared == _capi.ABI_VERSION
+
+
+def test_driver_entry_build_checks_the_current_abi():
+    """__graft_entry__.build() must compare against the mirror's ABI_VERSION, not a literal (it asserted version 1 for
+    a while after the ABI had moved to 2 and failed the driver's build check)."""
+    import inspect
+
+    import __graft_entry__ as entry
+    src = inspect.getsource(entry.build)
+    assert "ABI_VERSION" in src and not re.search(r"mppi_abi_version\(\)\s*==\s*\d", src)
 
 
 def test_config_struct_matches_header_size():
