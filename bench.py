@@ -12,7 +12,7 @@ Philox-keyed noise live on the GPU; nothing crosses PCIe inside the timed region
 The timed steps are the iterations of the reference driver's own run, episodes back to back: the robot starts at the
 head of the 100-waypoint path with a fresh controller and the loop runs tSim = 1000 iterations
 (mppi_differential_drive.py:396) -- some 25 of them traverse the path (the waypoint index moves, the search window is
-up to 100 candidates long and the sequential index needs repair launches: ~70 us per iteration), the rest hold the
+SEARCH_IDX_LEN = 20 candidates long (:204) and the sequential index needs repair launches: ~60 us per iteration), the rest hold the
 goal (window of one candidate: ~9 us).  A run that never leaves the hold phase would flatter the number, so the bench
 restarts the episode every 1000 iterations of its run (initialisation + warm-up + timed steps; three small uploads,
 timed when they fall into the timed region) -- with the default 2000 steps two traversals are inside the timed region --

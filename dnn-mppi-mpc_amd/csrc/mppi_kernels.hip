@@ -191,7 +191,7 @@ template <typename R, int MODEL> struct Rollout {
         } else {
             // lane t's first minimum over the window at the incoming index: from the LDS copy of the window at c in
             // one pass while the index still is c (one broadcast read per two candidates; walking the path with
-            // scalar loads cost every wave 2.8 us per 100 candidates), by the scalar walk below otherwise
+            // scalar loads costs a memory round trip per four candidates), by the scalar walk below otherwise
             int first_min = p;
             bool have_first_min = false;
             if (!slow) {  // does any call move the index away from p?

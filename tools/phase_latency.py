@@ -1,5 +1,5 @@
 """Diagnostic: latency of the two phases of the reference driver's run at BASELINE config 2 -- holding the goal (search
-window of one candidate) and traversing the path (window up to 100 candidates, repair launches for the sequential
+window of one candidate) and traversing the path (window of 20 candidates, repair launches for the sequential
 waypoint index).  MPPI_LIB=<other build> A/Bs two libraries on the same box.  Not part of the product or the tests."""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.getcwd())
