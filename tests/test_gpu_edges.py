@@ -189,6 +189,62 @@ def test_two_samples_per_wave_in_sequence(monkeypatch, case):
         test_long_horizon_racecar(monkeypatch, "1")
 
 
+def _curved_path(rng, kind, n):
+    """Paths whose nearest waypoint is NOT monotone along a rollout: a loop and a hairpin (the first minimum of a call
+    can lie behind the running index, or far ahead of it), besides the straight line of the reference's driver."""
+    s = np.linspace(0.0, 1.0, n)
+    if kind == "line":
+        x, y = 8.0 * s, -3.0 * s
+    elif kind == "loop":
+        a = 2.0 * np.pi * s
+        x, y = 3.0 * np.sin(a), 3.0 * np.sin(a) * np.cos(a)
+    else:  # hairpin: out and back, 0.4 apart
+        x = np.where(s < 0.5, 10.0 * s, 10.0 * (1.0 - s))
+        y = np.where(s < 0.5, 0.0, 0.4) + 0.05 * np.sin(20.0 * s)
+    yaw = np.arctan2(np.gradient(y), np.gradient(x))
+    return np.stack([x, y, yaw], axis=1)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sequential_index_exact_on_curved_paths(monkeypatch, seed):
+    """Randomised sweep of the reference-exact (sequential) waypoint index: curved paths, a start in the middle of the
+    path, every rollout layout.  Exercises what the straight path of the other tests does not: first minima behind
+    the running index (the search proper inside the threading), windows that stop short of the path's end, index
+    jumps of many waypoints -- the index, the costs and the controls must equal the oracle's over three iterations."""
+    import dnn_mppi_mpc_amd as pkg
+    rng = np.random.default_rng(7000 + seed)
+    kind = ("line", "loop", "hairpin")[seed % 3]
+    n_ref = int(rng.choice([30, 100, 260]))
+    K = int(rng.integers(1, 150))
+    T = int(rng.choice([10, 17, 40, 64, 65, 90, 128]))  # (the reference filter needs T >= 10)
+    monkeypatch.setenv("MPPI_DUAL", str(int(rng.integers(0, 2))))
+    monkeypatch.setenv("MPPI_PAIR", str(int(rng.integers(0, 2))))
+    monkeypatch.setenv("MPPI_SEQ", str(int(rng.integers(1, 3))))
+    kw = dd_case(rng, K, T, n_ref, int(rng.integers(0, 3)))
+    kw["ref_path"] = _curved_path(rng, kind, n_ref)
+    kw["max_speed"] = float(rng.uniform(1.0, 5.0))
+    i0 = int(rng.integers(0, max(1, n_ref // 2)))
+    x0 = kw["ref_path"][i0] + rng.normal(0, [0.15, 0.15, 0.3])
+    u_in = np.column_stack([rng.uniform(0.3, 1.0, T) * kw["max_speed"], rng.normal(0, 0.3, T)])
+    eps = philox.sample_epsilon(kw["sigma"], 31 + seed, 0, K, T)
+    o = mppi_oracle.DiffDriveOracle(**kw)
+    c = pkg.MPPIAlgorithms(**kw, precision="f64")
+    o.u_prev[:] = u_in
+    c.u_prev[:] = u_in
+    o.prev_way_point_idx = c.prev_way_point_idx = max(0, i0 - int(rng.integers(0, 4)))
+    c._calc_epsilon = lambda *a, **k: eps
+    for it in range(3):
+        ref = o.iteration(x0, eps.astype(np.float64))
+        u = c._calc_input_control(x0)[1]
+        assert c.prev_way_point_idx == ref["idx_after"], (kind, it)
+        S = c.sample_costs()
+        hit = ref["S"] > 1e9
+        np.testing.assert_array_equal(S > 1e9, hit)
+        np.testing.assert_allclose(S[~hit], ref["S"][~hit], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-7, atol=1e-9)
+        x0 = mppi_oracle.diffdrive_plant_step(x0, ref["u0_returned"], kw["delta_t"])
+
+
 def test_exchange_api_errors():
     """mppi_comm_*: call-order and mode errors are reported, the handle stays usable."""
     import dnn_mppi_mpc_amd as pkg
