@@ -245,6 +245,51 @@ def test_sequential_index_exact_on_curved_paths(monkeypatch, seed):
         x0 = mppi_oracle.diffdrive_plant_step(x0, ref["u0_returned"], kw["delta_t"])
 
 
+@pytest.mark.parametrize("model", ["diff", "race"])
+def test_more_than_64_obstacles(model):
+    """The obstacle table sits in the lanes of a wave (64 circles); the rest is read from memory.  70 small circles,
+    some of them on the path: the collision flags must equal the oracle's sample by sample."""
+    import dnn_mppi_mpc_amd as pkg
+    rng = np.random.default_rng(6464)
+    if model == "diff":
+        K, T = 200, 40
+        kw = dd_case(rng, K, T, 100, 0)
+        kw.update(obstacle_circles=np.column_stack([rng.uniform(0.3, 8, 70), rng.uniform(-5, 5, 70), rng.uniform(0.05, 0.25, 70)]),
+                  safety_margin_rate=0.8)
+        eps = philox.sample_epsilon(kw["sigma"], 5, 0, K, T)
+        o = mppi_oracle.DiffDriveOracle(**kw)
+        c = pkg.MPPIAlgorithms(**kw, precision="f64")
+        c._calc_epsilon = lambda *a, **k: eps
+        x0 = np.array([0.1, 0.0, -0.3])
+        ref = o.iteration(x0, eps.astype(np.float64))
+        u = c._calc_input_control(x0)[1]
+        hit = ref["S"] > 1e9
+        assert 0 < hit.sum() < K
+        np.testing.assert_array_equal(c.sample_costs() > 1e9, hit)
+        np.testing.assert_allclose(c.sample_costs()[~hit], ref["S"][~hit], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(u, ref["u_returned"], rtol=1e-7, atol=1e-9)
+    else:
+        K, T = 150, 75
+        lem = mppi_oracle.generate_lemniscate_racecar(80, 10.0)
+        circles = np.column_stack([rng.uniform(-12, 12, 90), rng.uniform(-8, 8, 90), rng.uniform(0.1, 0.5, 90)])
+        circles = circles[np.hypot(circles[:, 0] - lem[2, 0], circles[:, 1] - lem[2, 1]) > 4.0]  # none on the start pose
+        kw = dict(ref_path=lem, horizon_step_T=T, number_of_samples_K=K, param_exploration=0.1, param_alpha=0.9,
+                  obstacle_circles=circles, visualize_optimal_traj=True, visualze_sampled_trajs=False)
+        assert len(circles) > 64
+        eps = philox.sample_epsilon(np.array([[0.5, 0.0], [0.0, 0.1]]), 12, 0, K, T)
+        o = mppi_oracle.RaceCarOracle(**kw)
+        c = pkg.MPPIRacecarController(**kw, precision="f32")
+        c._calc_epsilon = lambda *a, **k: eps
+        ref = o.iteration(lem[2], eps)
+        u = c._calc_control_input(lem[2])[1]
+        hit = ref["S"] > 1e9
+        assert 0 < hit.sum() < K
+        # (a pose within f32 rounding of a circle could flip; none does with this seed)
+        np.testing.assert_array_equal(c.sample_costs() > 1e9, hit)
+        np.testing.assert_allclose(c.sample_costs()[~hit], ref["S"][~hit], rtol=3e-5, atol=1e-3)
+        assert rmse(u, ref["u_returned"]) <= 1e-4
+
+
 def test_exchange_api_errors():
     """mppi_comm_*: call-order and mode errors are reported, the handle stays usable."""
     import dnn_mppi_mpc_amd as pkg
