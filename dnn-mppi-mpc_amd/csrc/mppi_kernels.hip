@@ -492,6 +492,14 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     bool valid_first = false;
     int mover = NO_TRIGGER;  // the smaller of this half-wave's samples that moved the waypoint index (sequential mode)
     __shared__ int sh_mover[ROWS];
+    // `S[k] += ...` in the reference's order (f32 race car, see Rollout::chunk) for ALL samples of the workgroup at once:
+    // every (half-)wave leaves its per-step costs and the terminal cost in a row of LDS, then ONE wave adds them up with
+    // a lane per sample -- T + 1 dependent additions for the workgroup instead of for each of its waves (150 of the
+    // ~1000 VALU instructions a sample cost: the launch is VALU-bound).  Row pitch 129: a column is conflict-free.
+    constexpr bool F32 = sizeof(R) == 4;
+    const bool lds_sum = F32 && P.accumulate;
+    __shared__ float sh_st[F32 ? SAMPLES : 1][F32 ? 129 : 1];
+    const int sidx = wid * SPW + h;  // row of this (half-)wave; its first-pass sample sits ROWS further
 #pragma unroll
     for (int pass = 0; pass < SEQ; ++pass) {
     const int k = ((blockIdx.x * SEQ + pass) * DUAL_WAVES + wid) * SPW + h;  // this lane's sample
@@ -665,14 +673,17 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, lx, ly, lyaw, lvel);
             if (hit_l) term += P.penalty;
             STAMP(14);
-            const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
-            R acc_a = wv::read_lane(part, HL - 1), acc_b = wv::read_lane(part, 63);
-            if (sizeof(R) == 4) {  // a sample that collided: the reference's order of `S[k] += ...`, see Rollout::chunk
-                const unsigned long long hm = __ballot((a0 && hit0) || (a1 && hit1));
-                if ((SPW == 2 ? hm & 0xffffffffull : hm) != 0ull) acc_a = wv::ordered_sum2(R(0), st0, st1, 0, T);
-                if (SPW == 2 && (hm >> 32) != 0ull) acc_b = wv::ordered_sum2(R(0), st0, st1, 32, T);
+            if (F32) {  // (lds_sum) summed after the passes, a lane per sample
+                float *row = sh_st[(pass == SEQ - 1 ? 0 : ROWS) + sidx];
+                if (a0) row[t0] = (float)st0;
+                if (a1) row[t1] = (float)st1;
+                if (l32 == lane_last) row[T] = (float)term;
+                total = R(0);
+            } else {
+                const R part = wv::scan_incl_seg<wv::OpAdd, SPW>((a0 ? st0 : R(0)) + (a1 ? st1 : R(0)));
+                const R acc_a = wv::read_lane(part, HL - 1), acc_b = wv::read_lane(part, 63);
+                total = h ? acc_b + wv::read_lane(term, (SPW == 2 ? 32 : 0) + lane_last) : acc_a + wv::read_lane(term, lane_last);
             }
-            total = h ? acc_b + wv::read_lane(term, (SPW == 2 ? 32 : 0) + lane_last) : acc_a + wv::read_lane(term, lane_last);
         } else {  // `S[k] =`: only the last step's stage cost survives (:124)
             bool hit_l;
             const int idx_l = sub_last ? idx1 : idx0;
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         }
         S_k = total;
         if (l32 == 0 && live) {
-            S_[k] = total;
+            if (!lds_sum) S_[k] = total;
             pout_[k] = p_half;
         }
         if (live && P.sequential && p_half != c) mover = min(mover, k);  // (uniform within the half; SEQ passes ascend)
@@ -700,13 +711,34 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     STAMP(2);
 
     // ---- the workgroup's softmin record over its samples (S5-S6) -----------------------------------------------
-    const int sidx = wid * SPW + h;  // row of this (half-)wave; its first-pass sample sits ROWS further
-    if (l32 == 0) {
+    if (lds_sum) {
+        __syncthreads();
+        if (wid == 0 && lane < SAMPLES) {  // slot = lane: rows of the last pass first, then those of the first pass
+            const int pass_s = SEQ == 2 && lane < ROWS ? 1 : 0;
+            const int k_s = (blockIdx.x * SEQ + pass_s) * (DUAL_WAVES * SPW) + (lane % ROWS);
+            float S = INFINITY;
+            if (k_s < P.K) {
+                if (k_s >= k_start) {
+                    const float *row = sh_st[lane];
+                    S = 0.f;
+                    for (int t = 0; t <= T; ++t) S += row[t];
+                    S_[k_s] = (R)S;
+                } else {
+                    S = (float)S_[k_s];  // final from an earlier speculation round
+                }
+            }
+            sh_S[lane] = (R)S;
+        }
+    } else if (l32 == 0) {
         sh_S[sidx] = S_k;
         if (SEQ == 2) sh_S[ROWS + sidx] = S_first;
-        if (seq_search) sh_mover[sidx] = mover;
     }
+    if (l32 == 0 && seq_search) sh_mover[sidx] = mover;
     __syncthreads();
+    if (lds_sum) {
+        S_k = sh_S[sidx];
+        if (SEQ == 2) S_first = sh_S[ROWS + sidx];
+    }
     STAMP(3);
     R s_min = R(INFINITY);
 #pragma unroll

@@ -110,28 +110,6 @@ template <typename R> __device__ __forceinline__ R ordered_sum(R acc, R v, int f
     for (; i < n; ++i) acc += read_lane(v, first + i);
     return acc;
 }
-// two values per lane, lane-major: v0[first], v1[first], v0[first + 1], v1[first + 1], ... (n terms in all)
-template <typename R> __device__ __forceinline__ R ordered_sum2(R acc, R v0, R v1, int first, int n) {
-    const int nl = n >> 1;
-    int i = 0;
-    for (; i + 4 <= nl; i += 4) {
-        R a[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[2 * j] = read_lane(v0, first + i + j);
-            a[2 * j + 1] = read_lane(v1, first + i + j);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += a[j];
-    }
-    for (; i < nl; ++i) {
-        acc += read_lane(v0, first + i);
-        acc += read_lane(v1, first + i);
-    }
-    if (n & 1) acc += read_lane(v0, first + nl);
-    return acc;
-}
-
 template <typename Op, typename R> __device__ __forceinline__ R reduce(R x) {
     return read_lane(scan_incl<Op>(x), 63);
 }
