@@ -141,8 +141,10 @@ template <typename R> __device__ __forceinline__ ObsLanes<R> load_obstacles(cons
 
 // WIDE: the 8 outline points stay in registers and each circle is read once (the race-car kernels); otherwise the
 // points are visited one after the other, which keeps the diff-drive kernels at their register count
+// (`have_sc`: the caller already holds sin/cos of this yaw)
 template <bool WIDE, typename R>
-__device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, const ObsLanes<R> &tab) {
+__device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, const ObsLanes<R> &tab, bool have_sc = false,
+                                         R sn_in = R(0), R cs_in = R(1)) {
     if (P.obstacle_model == OBS_NONE) return false;
     bool hit = false;
     const int n_reg = P.n_obs < 64 ? P.n_obs : 64;
@@ -158,8 +160,8 @@ __device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, c
         return hit;
     }
     // OBS_OUTLINE; the reference's 9th point repeats the 1st (mppi_race_car_obstacle.py:263-264)
-    R sn, cs;
-    mf::sincos_(yaw, sn, cs);
+    R sn = sn_in, cs = cs_in;
+    if (!have_sc) mf::sincos_(yaw, sn, cs);
     if (WIDE) {
         // The outline is the reference's fixed pattern -- (+-a, 0), (+-a, +-b), (0, +-b) in the body frame, a and b half the
         // scaled length and width (:260-261) -- and closed under mirroring in both axes.  So instead of rotating eight

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         // ---- dynamics: scans over the lane totals of each half, then one add for the lane's second step ----
         const R x_0 = (R)sv.x0[0], y_0 = (R)sv.x0[1], yaw_0 = (R)sv.x0[2];
         R px0, py0, yw0, vl0 = 0, px1, py1, yw1, vl1 = 0;  // state after the lane's first / second step
+        R sin_w0 = 0, cos_w0 = 1;  // sin/cos(yw0): the dynamics of the second step need it, so does the outline test of the first
         if (MODEL == MODEL_DIFF) {  // :194-196
             const R d0 = v01 * P.dt, d1 = v11 * P.dt;
             const R yb0 = yaw_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(d0 + d1), R(0));
@@ -555,6 +556,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             R s0, c0, s1, c1;
             mf::sincos_(yb0, s0, c0);
             mf::sincos_(yw0, s1, c1);
+            sin_w0 = s1;
+            cos_w0 = c1;
             const R dx0 = v00 * c0 * P.dt, dx1 = v10 * c1 * P.dt, dy0 = v00 * s0 * P.dt, dy1 = v10 * s1 * P.dt;
             px0 = x_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dx0 + dx1), R(0)) + dx0;
             px1 = px0 + dx1;
@@ -574,6 +577,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
             R s0, c0, s1, c1;
             mf::sincos_(yb0, s0, c0);
             mf::sincos_(yw0, s1, c1);
+            sin_w0 = s1;
+            cos_w0 = c1;
             const R dx0 = a0 ? vb0 * c0 * P.dt : R(0), dx1 = a1 ? vl0 * c1 * P.dt : R(0);
             const R dy0 = a0 ? vb0 * s0 * P.dt : R(0), dy1 = a1 ? vl0 * s1 * P.dt : R(0);
             px0 = x_0 + wv::shift_up1_seg<SPW>(wv::scan_incl_seg<wv::OpAdd, SPW>(dx0 + dx1), R(0)) + dx0;
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         STAMP(11);
 
         // ---- costs -----------------------------------------------------------------------------------------------
-        auto stage_cost = [&](R x, R y, R yaw, R vel, int idx, R ua, R ub, R va, R vb, bool &hit) {
-            hit = collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs);
+        auto stage_cost = [&](R x, R y, R yaw, R vel, int idx, R ua, R ub, R va, R vb, bool &hit, bool have_sc = false) {
+            hit = collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs, have_sc, sin_w0, cos_w0);
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
         R total;
         if (P.accumulate) {
             bool hit0, hit1;
-            const R st0 = stage_cost(px0, py0, yw0, vl0, idx0, u00, u01, v00, v01, hit0);
+            const R st0 = stage_cost(px0, py0, yw0, vl0, idx0, u00, u01, v00, v01, hit0, true);
             STAMP(12);
             const R st1 = stage_cost(px1, py1, yw1, vl1, idx1, u10, u11, v10, v11, hit1);
             STAMP(13);
