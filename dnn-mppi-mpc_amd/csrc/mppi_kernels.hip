@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64) void k_set_state(const R *ref, int n_ref, int w
 // ------------------------------------------------------------------------------------------
 // S2-S4: perturb + clamp, rollout, cost.  One wave per sample, lanes over the horizon.
 // ------------------------------------------------------------------------------------------
-template <typename R, int MODEL> struct Rollout {
+// OBS = false: a handle without obstacles compiles to the kernel without the obstacle table and the collision tests
+template <typename R, int MODEL, bool OBS = true> struct Rollout {
     const KParams<R> &P;
     const int k, lane, c;
     const unsigned iter;
@@ -252,7 +253,7 @@ template <typename R, int MODEL> struct Rollout {
         // ---- stage cost of every call (only the last one survives when !accumulate) ------
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
-            const bool hit = collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs);
+            const bool hit = OBS ? collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs) : false;
             R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, my_idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
@@ -345,7 +346,7 @@ template <int N> __device__ __forceinline__ void publish_first_mover(const int *
 
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
-template <typename R, int MODEL, int NCH, bool MULTI>
+template <typename R, int MODEL, int NCH, bool MULTI, bool OBS>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevState *st_pre, const KParams<R> P,
                                                                     R *__restrict__ partials) {
     const int agent = MULTI ? (int)blockIdx.y : 0;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     STAMP(1);
     const bool valid = k < P.K;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
-    const ObsLanes<R> obs = load_obstacles(P, lane);
+    const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     // Both waypoint modes search the window at c first.  A sequential-mode window of ONE candidate (the robot holds
     // the end of the path) leaves nothing to search or to move: no staging and no barrier behind its loads then
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
+        Rollout<R, MODEL, OBS> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
         r.sh_first = seq_search ? &sh_first : nullptr;
         if (k >= k_start) {
 #pragma unroll
@@ -1644,8 +1645,13 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
         else hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
         break;
     default:
-        if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
-        else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        if (P.obstacle_model == OBS_NONE) {
+            if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI, false>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+            else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI, false>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        } else {
+            if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI, true>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+            else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI, true>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        }
     }
 }
 template <typename R, int MODEL> static void launch_fused_m(const KParams<R> &P, R *partials, hipStream_t s) {
