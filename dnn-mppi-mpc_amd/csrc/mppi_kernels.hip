@@ -365,11 +365,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
-    // Both waypoint modes search the window at c first.  A sequential-mode window of ONE candidate (the robot holds
-    // the end of the path) leaves nothing to search or to move: no staging and no barrier behind its loads then
-    // (0.7 us per launch at config 2).
+    // Both waypoint modes search the window at c first.  A window of ONE candidate (the robot holds the end of the
+    // path) leaves nothing to search or to move: no staging and no barrier behind its loads then (0.7 us per launch
+    // at config 2).
     const bool seq_search = P.sequential && wlen0 > 1;
-    const bool use_win = wlen0 <= WINDOW_LDS_MAX && (seq_search || !P.sequential);
+    const bool use_win = wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
     __shared__ int sh_mover[FUSED_WAVES];
     __shared__ int sh_first;
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState
     const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, c);
     const bool seq_search = P.sequential && wlen0 > 1;  // (see k_rollout_fused)
-    const bool use_win = wlen0 <= WINDOW_LDS_MAX && (seq_search || !P.sequential);
+    const bool use_win = wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
     __shared__ int sh_first;  // smallest sample of the workgroup that moved the index so far (see Rollout::chunk)
     if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
     if (seq_search && threadIdx.x == 0) sh_first = NO_TRIGGER;
