@@ -84,8 +84,15 @@ __global__ __launch_bounds__(64) void k_set_state(const R *ref, int n_ref, int w
 // ------------------------------------------------------------------------------------------
 // S2-S4: perturb + clamp, rollout, cost.  One wave per sample, lanes over the horizon.
 // ------------------------------------------------------------------------------------------
-// OBS = false: a handle without obstacles compiles to the kernel without the obstacle table and the collision tests
-template <typename R, int MODEL, bool OBS = true> struct Rollout {
+// OBS = false: a handle without obstacles compiles to the kernel without the obstacle table and the collision tests.
+// PLAIN: in addition the noise is drawn in the kernel, the rollout clamps its controls and no cost wraps the yaw -- the
+// reference's diff-drive NumPy controller as bench.py runs it; the four run-time switches become constants (0.19 us per
+// iteration at config 2, A/B on one box).  Anything else takes the general instantiation.
+template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rollout {
+    __device__ __forceinline__ bool use_philox() const { return PLAIN || P.use_philox; }
+    __device__ __forceinline__ bool clamp_rollout() const { return PLAIN || P.clamp_rollout; }
+    __device__ __forceinline__ bool wrap_stage() const { return !PLAIN && P.wrap_stage; }
+    __device__ __forceinline__ bool wrap_term() const { return !PLAIN && P.wrap_term; }
     const KParams<R> &P;
     const int k, lane, c;
     const unsigned iter;
@@ -115,7 +122,7 @@ template <typename R, int MODEL, bool OBS = true> struct Rollout {
         e0 = 0.f;
         e1 = 0.f;
         if (t < P.T) {
-            if (P.use_philox) {
+            if (use_philox()) {
                 px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1,
                            (unsigned)(P.noise_stream + agent));
             } else {
@@ -141,7 +148,7 @@ template <typename R, int MODEL, bool OBS = true> struct Rollout {
             u1 = u[2 * t + 1];
         }
         R v0 = exploit ? u0 + (R)e0 : (R)e0, v1 = exploit ? u1 + (R)e1 : (R)e1;  // :116-119
-        if (P.clamp_rollout) {                                                   // `_g` :285-289
+        if (clamp_rollout()) {                                                   // `_g` :285-289
             v0 = mf::clamp(v0, P.umax0);
             v1 = mf::clamp(v1, P.umax1);
         }
@@ -254,7 +261,7 @@ template <typename R, int MODEL, bool OBS = true> struct Rollout {
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
             const bool hit = OBS ? collided<MODEL == MODEL_RACE>(P, x, y, yaw, obs) : false;
-            R st_c = tracking_cost<R, MODEL>(P, P.ws, P.wrap_stage, my_idx, x, y, yaw, vel);
+            R st_c = tracking_cost<R, MODEL>(P, P.ws, wrap_stage(), my_idx, x, y, yaw, vel);
             if (hit) st_c += P.penalty;
             R ctrl;
             if (MODEL == MODEL_DIFF)  // u^T Sigma^-1 v, :124
@@ -285,7 +292,7 @@ template <typename R, int MODEL, bool OBS = true> struct Rollout {
                     p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                     idx_term = p;
                 }
-                R term = tracking_cost<R, MODEL>(P, P.wt, P.wrap_term, idx_term, x, y, yaw, vel);
+                R term = tracking_cost<R, MODEL>(P, P.wt, wrap_term(), idx_term, x, y, yaw, vel);
                 if (hit) term += P.penalty;
                 s_last = P.accumulate ? term : stage + term;
             }
@@ -346,9 +353,11 @@ template <int N> __device__ __forceinline__ void publish_first_mover(const int *
 
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
-template <typename R, int MODEL, int NCH, bool MULTI, bool OBS>
+// SPEC: 0 general, 1 no obstacles, 2 no obstacles + the PLAIN switches (see Rollout)
+template <typename R, int MODEL, int NCH, bool MULTI, int SPEC>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevState *st_pre, const KParams<R> P,
                                                                     R *__restrict__ partials) {
+    constexpr bool OBS = SPEC == 0, PLAIN = SPEC == 2;
     const int agent = MULTI ? (int)blockIdx.y : 0;
     __shared__ R sh_S[FUSED_WAVES];
     __shared__ R sh_e[FUSED_WAVES];
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
     if (valid) {
-        Rollout<R, MODEL, OBS> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
+        Rollout<R, MODEL, OBS, PLAIN> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
         r.sh_first = seq_search ? &sh_first : nullptr;
         if (k >= k_start) {
 #pragma unroll
@@ -1645,12 +1654,22 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
         else hipLaunchKernelGGL((k_rollout_dual<R, MODEL, 1, MULTI, 1>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
         break;
     default:
-        if (P.obstacle_model == OBS_NONE) {
-            if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI, false>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
-            else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI, false>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
-        } else {
-            if (P.T <= 64) hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 1, MULTI, true>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
-            else hipLaunchKernelGGL((k_rollout_fused<R, MODEL, 2, MULTI, true>), grid, dim3(64 * FUSED_WAVES), 0, s, P.st, P, partials);
+        {
+            const bool plain = P.obstacle_model == OBS_NONE && P.use_philox && P.clamp_rollout && !P.wrap_stage && !P.wrap_term;
+            const int spec = plain ? 2 : P.obstacle_model == OBS_NONE ? 1 : 0;
+            const dim3 block(64 * FUSED_WAVES);
+#define MPPI_LAUNCH_FUSED(NCH_, SPEC_) \
+    hipLaunchKernelGGL((k_rollout_fused<R, MODEL, NCH_, MULTI, SPEC_>), grid, block, 0, s, P.st, P, partials)
+            if (P.T <= 64) {
+                if (spec == 2) MPPI_LAUNCH_FUSED(1, 2);
+                else if (spec == 1) MPPI_LAUNCH_FUSED(1, 1);
+                else MPPI_LAUNCH_FUSED(1, 0);
+            } else {
+                if (spec == 2) MPPI_LAUNCH_FUSED(2, 2);
+                else if (spec == 1) MPPI_LAUNCH_FUSED(2, 1);
+                else MPPI_LAUNCH_FUSED(2, 0);
+            }
+#undef MPPI_LAUNCH_FUSED
         }
     }
 }
