@@ -242,7 +242,7 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_file):  # rocprofv3 --pmc passes of this same command (see profiles/README.md)
             traffic = json.load(open(pmc_file)).get("k_rollout_fused_hbm_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": "k_rollout_fused<float, diffdrive, 1>",
+        roof = {"bound": "hbm", "kernel": "k_rollout_fused<float, diffdrive, 1 chunk, single agent, PLAIN>",
                 "achieved": alg_bytes / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / t_roll / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
