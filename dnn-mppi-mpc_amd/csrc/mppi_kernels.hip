@@ -1197,11 +1197,17 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 // workgroup of NT threads; state and controls are updated where they are or into F.st_out / F.u_out.
 // The *_pre arguments repeat F.partials, F.heads, F.st, F.u and F.T: leading kernel arguments that the dispatcher
 // preloads into SGPRs (-amdgpu-kernarg-preload-count), so the first loads do not wait for the argument fetch.
-template <typename A, int MODE, int NT, int NWIN>
+// PLAIN: the closed loop of the diff-drive NumPy controller on one GPU (sequential index, its moving average, the plant
+// on the device, no host arguments, no trace) -- the run-time switches below are constants then (0.15 us per iteration at
+// config 2, A/B on one box); launch_finalize picks it when every condition holds.
+template <typename A, int MODE, int NT, int NWIN, bool PLAIN = false>
 __device__ __forceinline__ void finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
                                               const void *u_pre, int T_pre, const FinalizeParams &F, char *smem,
                                               int agent) {
     constexpr bool ABI_RECS = MODE == 1, XCHG = MODE == 2;
+    const bool f_use_args = !PLAIN && F.use_args, f_sequential = PLAIN || F.sequential, f_plant = PLAIN || F.plant;
+    const bool f_raise = !PLAIN && F.raise_at_path_end, f_clamp_u = !PLAIN && F.clamp_u, f_trace = !PLAIN && F.u0_trace != nullptr;
+    const int f_model = PLAIN ? (int)MODEL_DIFF : F.model, f_filter = PLAIN ? (int)FILTER_DIFF : F.filter_mode;
     static_assert(MODE == 0 || NT == MERGE_THREADS, "the ABI / exchange variants are 256-thread kernels");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int T = F.T, W = F.filter_window, H = W / 2;
@@ -1250,9 +1256,9 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     }
     const int fk = sv.first_k, round = sv.round;
     // first round of a synchronous step: the observed state and its x0 index came as kernel arguments
-    const bool args = F.use_args && round == 0;
+    const bool args = f_use_args && round == 0;
     const int c_state = args ? F.c_arg : sv.c;
-    const int p_state = (args && !F.sequential) ? F.c_arg : sv.p;  // update_prev_idx=True at x0 (mppi_race_car.py:61)
+    const int p_state = (args && !f_sequential) ? F.c_arg : sv.p;  // update_prev_idx=True at x0 (mppi_race_car.py:61)
     const int idx_start = args ? F.c_arg : sv.idx_start, path_end = args ? (F.c_arg >= F.n_ref - 1) : sv.path_end;
     const long long iter = sv.iter;
     const double x0v[4] = {args ? F.x0_arg[0] : sv.x0[0], args ? F.x0_arg[1] : sv.x0[1],
@@ -1283,7 +1289,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     }
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
     int c_final = c_state;
-    if (F.sequential && fk != NO_TRIGGER) {
+    if (f_sequential && fk != NO_TRIGGER) {
         const int c_new = pout[fk];
         if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
             nx.k_start = fk + 1;
@@ -1300,23 +1306,23 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         }
         c_final = c_new;
     }
-    const int p_now = F.sequential ? c_final : p_state;  // prev_way_point_idx after this iteration
+    const int p_now = f_sequential ? c_final : p_state;  // prev_way_point_idx after this iteration
 
     // wave 0 prefetches the candidates of the next x0 call so that they overlap the merge
     A cand_x = 0, cand_y = 0;
     const int wlen_next = min(F.window, F.n_ref - p_now);
-    if (wid == 0 && F.plant && lane < wlen_next) {
+    if (wid == 0 && f_plant && lane < wlen_next) {
         cand_x = ref[4 * (p_now + lane)];
         cand_y = ref[4 * (p_now + lane) + 1];
     }
     A sn_yaw = 0, cs_yaw = 1;  // the plant's trigonometry, while the loads are in flight
-    if (F.plant) mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
+    if (f_plant) mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
     STAMP(17);
 
     // w_eps lands in the padded layout the filter reads: H leading and W - H trailing slots hold zeros
     // (np.convolve 'same', mppi_differential_drive.py:257-263) or copies of the first / last H samples
     // (mppi_race_car.py:211-222: the padded signal is xx[:H] + xx + xx[-H:])
-    const bool pad_copy = F.filter_mode == FILTER_RACE || F.filter_mode == FILTER_TORCH;
+    const bool pad_copy = f_filter == FILTER_RACE || f_filter == FILTER_TORCH;
     auto store_w = [&](int i, A v) {
         const int t = i >> 1, d = i & 1;
         const A pv = pad_copy ? v : A(0);
@@ -1364,7 +1370,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     }
     STAMP(18);
 
-    if (F.raise_at_path_end && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
+    if (f_raise && path_end) {  // mppi_race_car.py:63-65: nothing is updated (but the index was, :61)
         nx.k_start = 0;
         nx.round = 0;
         if (tid == 0) {
@@ -1380,9 +1386,9 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     for (int i = tid; i < 2 * T; i += NT) {
         const int t = i >> 1, d = i & 1;
         A f;
-        if (F.filter_mode == FILTER_NONE) {
+        if (f_filter == FILTER_NONE) {
             f = sh_w[2 * (t + H) + d];
-        } else if (F.filter_mode == FILTER_TORCH) {
+        } else if (f_filter == FILTER_TORCH) {
             // conv1d(padding = H) over the padded signal, first T outputs (mppi_race_car_torch.py:211-222):
             // output t = padded rows t-H .. t-H+W-1, rows before the start are the convolution's zero padding
             A sacc = 0;
@@ -1400,7 +1406,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             } else {
                 for (int q = 0; q < W; ++q) sacc += tap[2 * (W - 1 - q)] * inv_w;
             }
-            if (F.filter_mode == FILTER_DIFF) {  // the edge factors of mppi_differential_drive.py:265-269
+            if (f_filter == FILTER_DIFF) {  // the edge factors of mppi_differential_drive.py:265-269
                 const int n_conv = (W + 1) / 2;
                 if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
                 else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
@@ -1411,7 +1417,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         }
         const A uo = i == tid ? u_old : u_in[i];
         A un = uo + f;                                                        // u += w_epsilon, :141
-        if (F.clamp_u) un = mf::clamp(un, d == 0 ? (A)F.umax0 : (A)F.umax1);  // :145-149
+        if (f_clamp_u) un = mf::clamp(un, d == 0 ? (A)F.umax0 : (A)F.umax1);  // :145-149
         sh_u[i] = un;
     }
     __syncthreads();
@@ -1431,8 +1437,8 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     if (wid == 0) {
         const A u0a = sh_u[2 * (T > 1 ? 1 : 0)], u0b = sh_u[2 * (T > 1 ? 1 : 0) + 1];
         double xn[4] = {x0v[0], x0v[1], x0v[2], x0v[3]};
-        if (F.plant) {  // the driver's plant with the returned control
-            if (F.model == MODEL_DIFF) {  // DifferentialDrive.update_state :33-40
+        if (f_plant) {  // the driver's plant with the returned control
+            if (f_model == MODEL_DIFF) {  // DifferentialDrive.update_state :33-40
                 xn[0] += (double)(u0a * cs_yaw) * F.dt;
                 xn[1] += (double)(u0a * sn_yaw) * F.dt;
                 xn[2] += (double)u0b * F.dt;
@@ -1459,10 +1465,10 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             res->rho = (double)rho; res->eta = (double)eta; res->ess = (double)(eta * eta / eta2);
             res->u0[0] = (double)u0a; res->u0[1] = (double)u0b;
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];
-            if (F.u0_trace && agent == 0) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
+            if (f_trace && agent == 0) { F.u0_trace[2 * iter] = (double)u0a; F.u0_trace[2 * iter + 1] = (double)u0b; }
             res->iter = iter + 1;
         }
-        if (F.plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
+        if (f_plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
             A best = A(INFINITY);
             int bj = INT_MAX;
             const A xq = (A)xn[0], yq = (A)xn[1];
@@ -1482,7 +1488,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             nx.c = c;
             nx.idx_start = c;
             nx.path_end = c >= F.n_ref - 1;
-            if (!F.sequential) nx.p = c;
+            if (!f_sequential) nx.p = c;
         }
         if (lane == 0) *st_out = nx;
     }
@@ -1490,7 +1496,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     STAMP(21);
 }
 
-template <typename A, int MODE, int NWIN, bool MULTI>
+template <typename A, int MODE, int NWIN, bool MULTI, bool PLAIN = false>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
                                                             const DevState *st_pre, const void *u_pre, int T_pre,
                                                             const FinalizeParams F) {
@@ -1503,7 +1509,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                                                     st_pre + a, reinterpret_cast<const A *>(u_pre) + (size_t)a * 2 * T_pre,
                                                     T_pre, F, smem, a);
     } else {
-        finalize_body<A, MODE, MERGE_THREADS, NWIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, 0);
+        finalize_body<A, MODE, MERGE_THREADS, NWIN, PLAIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, 0);
     }
 }
 
@@ -1727,7 +1733,12 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_rec
     if (abi_recs) MPPI_FIN(1, 1, false);
     else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2, false); else MPPI_FIN(2, 1, false); }
     else if (multi) { if (two) MPPI_FIN(0, 2, true); else MPPI_FIN(0, 1, true); }
-    else { if (two) MPPI_FIN(0, 2, false); else MPPI_FIN(0, 1, false); }
+    else if (two) MPPI_FIN(0, 2, false);
+    else if (F.sequential && F.plant && !F.use_args && !F.raise_at_path_end && !F.clamp_u && F.model == MODEL_DIFF &&
+             !F.u0_trace && F.filter_mode == FILTER_DIFF)
+        hipLaunchKernelGGL((k_finalize<R, 0, 1, false, true>), grid, dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,
+                           (const void *)F.u, F.T, F);
+    else MPPI_FIN(0, 1, false);
 #undef MPPI_FIN
 }
 

@@ -344,6 +344,34 @@ def test_restart_episode_reproduces_a_fresh_controller():
     assert st_a.idx_after == st_b.idx_after and st_a.idx_after > 0
 
 
+def test_specialised_closed_loop_kernels_equal_the_general_ones():
+    """The closed loop of the diff-drive NumPy controller runs the PLAIN instantiations of k_rollout_fused and
+    k_finalize (run-time switches as constants); asking for the u0 trace selects the general k_finalize, injected noise
+    the general rollout.  Same run, bit for bit."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(2048, 40)
+    a = pkg.MPPIAlgorithms(**kw, precision="f32", seed=21)
+    b = pkg.MPPIAlgorithms(**kw, precision="f32", seed=21)
+    for c in (a, b):
+        c._engine.set_state(np.array([0.1, -0.05, 0.2]))
+    n = 60  # traversal of the path and the first iterations at its end
+    a._engine.run_closed_loop(n)                       # PLAIN rollout + PLAIN finalize
+    tr, st_b = b._engine.run_closed_loop(n, trace=True)  # PLAIN rollout + general finalize
+    np.testing.assert_array_equal(a._engine.get_state(), b._engine.get_state())
+    np.testing.assert_array_equal(a._engine.get_u_prev(), b._engine.get_u_prev())
+    assert a._engine.get_waypoint_idx() == b._engine.get_waypoint_idx() == st_b.idx_after
+    # general rollout (noise handed over as a tensor) against the PLAIN one (drawn in the kernel), one iteration
+    x0 = np.array([0.3, -0.1, -0.4])
+    c1 = pkg.MPPIAlgorithms(**kw, precision="f32", seed=5)
+    c2 = pkg.MPPIAlgorithms(**kw, precision="f32", seed=5)
+    eps = c2._engine.sample_epsilon(0)
+    c2._calc_epsilon = lambda *aa, _e=eps, **k: _e
+    u1 = c1._calc_input_control(x0)[1].copy()
+    u2 = c2._calc_input_control(x0)[1].copy()
+    np.testing.assert_array_equal(c1.sample_costs(), c2.sample_costs())
+    np.testing.assert_array_equal(u1, u2)
+
+
 def test_fused_and_unfused_paths_agree(monkeypatch):
     """T <= 128 runs rollout+softmin partial in one launch; MPPI_FORCE_UNFUSED=1 selects the separate
     k_rollout / k_reduce launches (the only path for longer horizons).  Same iteration either way."""
