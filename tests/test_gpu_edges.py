@@ -153,14 +153,17 @@ def test_long_horizon_layouts_match_oracle(monkeypatch, pair, K, T, obstacles):
 
 
 @pytest.mark.parametrize("pair", ["0", "1"])
-def test_long_horizon_racecar(monkeypatch, pair):
+@pytest.mark.parametrize("T,K", [(75, 150), (128, 37), (65, 16), (127, 300)])
+def test_long_horizon_racecar(monkeypatch, pair, T, K):
+    """64 < T <= 128 with the f32 `S[k] +=` order: both layouts; T = 128 fills the last column of the cost rows the
+    workgroup-wide ordered sum keeps in LDS."""
     import dnn_mppi_mpc_amd as pkg
     monkeypatch.setenv("MPPI_PAIR", pair)
     lem = mppi_oracle.generate_lemniscate_racecar(80, 10.0)
-    kw = dict(ref_path=lem, horizon_step_T=75, number_of_samples_K=150, param_exploration=0.1, param_alpha=0.9,
+    kw = dict(ref_path=lem, horizon_step_T=T, number_of_samples_K=K, param_exploration=0.1, param_alpha=0.9,
               obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), visualize_optimal_traj=True,
               visualze_sampled_trajs=False)
-    eps = philox.sample_epsilon(np.array([[0.5, 0.0], [0.0, 0.1]]), 11, 0, 150, 75)
+    eps = philox.sample_epsilon(np.array([[0.5, 0.0], [0.0, 0.1]]), 11, 0, K, T)
     o = mppi_oracle.RaceCarOracle(**kw)
     c = pkg.MPPIRacecarController(**kw, precision="f32")
     c._calc_epsilon = lambda *a, **k: eps
@@ -186,7 +189,8 @@ def test_two_samples_per_wave_in_sequence(monkeypatch, case):
         for K, T in [(19, 5), (65, 63), (130, 30)]:
             test_ragged_racecar_shapes_match_oracle(monkeypatch, "1", K, T)
     else:
-        test_long_horizon_racecar(monkeypatch, "1")
+        for T, K in [(75, 150), (128, 37)]:
+            test_long_horizon_racecar(monkeypatch, "1", T, K)
 
 
 def _curved_path(rng, kind, n):
