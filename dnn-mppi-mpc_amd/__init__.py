@@ -8,7 +8,7 @@ hand-written HIP for gfx950 in lib/libmppi_hip.so (C ABI: include/mppi_hip.h).
 """
 from . import _capi
 from ._capi import MppiError, load_library
-from .build import build as build_library
+from .build import build as build_library, source_id
 from .controllers import MPPIAlgorithms, MPPIRacecarController
 from .engine import Engine
 from . import paths

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
+ABI_VERSION = 3  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
 LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.so")  # MPPI_LIB: A/B a diagnostic build
 
 # enums of mppi_hip.h
@@ -92,6 +92,7 @@ PROTOTYPES = {
     "mppi_last_kernel_ms": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "mppi_enable_timing": (C.c_int, [_H, C.c_int32]),
     "mppi_set_rollout_repeats": (C.c_int, [_H, C.c_int32]),
+    "mppi_get_counters": (C.c_int, [_H, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

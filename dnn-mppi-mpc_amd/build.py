@@ -18,6 +18,20 @@ def lib_is_stale() -> bool:
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def source_id() -> str:
+    """Identity of the kernel sources (sha256 over csrc/*.hip, csrc/*.h, include/mppi_hip.h, 16 hex digits): profile
+    summaries under profiles/ carry it, and bench.py quotes a counter-derived figure only from a profile of THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(PKG), "include", "mppi_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -shared ... -> lib/libmppi_hip.so; returns its path."""
     if force or lib_is_stale():

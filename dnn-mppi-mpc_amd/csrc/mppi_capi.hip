@@ -58,6 +58,7 @@ struct mppi_handle {
     char **d_xpeers = nullptr;       // device array [x_nranks]
     int *d_xerr = nullptr, *d_xok = nullptr;
     long long xseq = 0, x_timeout = 300000000LL;
+    long long n_rollout_launches = 0, n_finalize_launches = 0;  // mppi_get_counters
     std::string err;
 };
 
@@ -171,6 +172,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
         FAIL((mppi_handle *)nullptr, MPPI_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
              c.device, prop.gcnArchName);
 
+    if (c.n_agents > 1 && getenv("MPPI_FORCE_UNFUSED"))
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED, "several agents per handle need the fused rollout kernels");
     mppi_handle *h = new mppi_handle();
     h->cfg = c;
     h->f64 = c.precision == MPPI_PREC_F64;
@@ -196,8 +199,6 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipSetDevice(c.device)) != hipSuccess) return fail(e, "hipSetDevice");
     const size_t r = rsz(h), B = (size_t)c.n_agents;
     h->B = c.n_agents;
-    if (c.n_agents > 1 && getenv("MPPI_FORCE_UNFUSED"))
-        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED, "several agents per handle need the fused rollout kernels");
     if ((e = hipMalloc(&h->d_u, B * r * 2 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u)");
     if ((e = hipMalloc(&h->d_uhist, B * r * 4 * c.T)) != hipSuccess) return fail(e, "hipMalloc(u history)");
     if ((e = hipMalloc(&h->d_S, B * r * c.K)) != hipSuccess) return fail(e, "hipMalloc(S)");
@@ -217,6 +218,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->res_bytes = (h->res_bytes + 15) & ~(size_t)15;  // (the agents' results are stored back to back)
     if ((e = hipMalloc((void **)&h->d_st, B * sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, B * h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
+    if ((e = hipMemset(h->d_res, 0, B * h->res_bytes)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipHostMalloc((void **)&h->h_res, B * h->res_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return fail(e, "hipHostMalloc(result)");
     if ((e = hipHostGetDevicePointer((void **)&h->res_mapped, h->h_res, 0)) != hipSuccess)
@@ -271,6 +273,7 @@ extern "C" int mppi_set_ref_path(mppi_handle *h, const double *path, int32_t n, 
     h->d_ref = nullptr;
     HIPCHECK(h, hipMalloc(&h->d_ref, rsz(h) * 4 * n));
     h->n_ref = n;
+    h->dev_loop_primed = false;
     h->ref_host = packed;
     if (!h->f64)
         for (double &v : h->ref_host) v = (double)(float)v;
@@ -354,6 +357,7 @@ extern "C" int mppi_set_waypoint_idx(mppi_handle *h, int32_t idx) {
     for (int a = 0; a < h->B; ++a)  // (every agent of a batched handle)
         HIPCHECK(h, hipMemcpy(&h->d_st[a].p, &idx, sizeof(int), hipMemcpyHostToDevice));
     h->idx = idx;
+    h->dev_loop_primed = false;
     return MPPI_OK;
 }
 
@@ -551,6 +555,7 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
                          const void **heads, int *n_recs, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
     const bool mlp = h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP;
+    h->n_rollout_launches += h->rollout_repeats;
     for (int rep = 0; rep < h->rollout_repeats; ++rep) {
         if (mlp) launch_mlp(h, P, s);
         else if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
@@ -575,6 +580,7 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
 template <typename R>
 static void launch_back(mppi_handle *h, const FinalizeParams &F, bool abi_recs, hipStream_t s, bool tm) {
     if (tm) hipEventRecord(next_event(h), s);
+    ++h->n_finalize_launches;
     launch_finalize<R>(F, abi_recs, s);
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);  // empty pair: the cost of the bracketing itself
@@ -700,6 +706,7 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
     for (int round = 0;; ++round) {
         F.seq = h->poll ? ++h->seq : 0;
         launch_slot<R>(h, P, F, s);
+        HIPCHECK(h, hipGetLastError());  // a refused launch would otherwise show only as the poll's timeout
         int rc = wait_result(h, F.seq, s);
         if (rc) return rc;
         if (h->h_res->status != STATUS_NEED_ROUND) break;
@@ -933,6 +940,10 @@ extern "C" int mppi_comm_export(mppi_handle *h, int32_t nranks, void *handle_out
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_export: nranks must be 2..%d (got %d)", XCHG_MAX_RANKS, nranks);
     if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
         FAIL(h, MPPI_ERR_UNSUPPORTED, "the exchange needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
+    // the finalize kernel stages up to XCHG_LDS_RANKS rank records in LDS next to its merge workspace
+    if (merge_lds_elems(h->cfg.T, h->cfg.filter_window, rsz(h)) * rsz(h) + sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(h->cfg.T) > 64 * 1024)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "the peer-to-peer exchange stages the rank records in LDS: horizon T=%d is too long for it "
+                                      "(use the split step with a collective)", h->cfg.T);
     if (h->xbuf) mppi_comm_close(h);
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     h->xbuf_bytes = 2 * xchg_slot_bytes(h->cfg.T, nranks);
@@ -1023,7 +1034,11 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         F.u0_trace = h->d_trace - 2 * h->iter;  // the kernel indexes by the absolute iteration
     }
     const long long target = h->iter + n_iters;
-    launch_set_state<R>(P, nullptr, s);  // x0 call for the state already on the device
+    // x0 call for the state already on the device -- unless the finalize kernel of the previous closed-loop iteration
+    // has made it (a second call would search from the index the first one left: with the frozen index that is c, not
+    // prev_waypoints_idx, and the result would depend on how a run is cut into calls)
+    if (!h->dev_loop_primed) launch_set_state<R>(P, nullptr, s);
+    h->dev_loop_primed = false;
     long long done = h->iter;
     int guard = 0;
     while (done < target) {
@@ -1052,6 +1067,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     if (u0_trace)
         HIPCHECK(h, hipMemcpy(u0_trace, h->d_trace, sizeof(double) * 2 * n_iters, hipMemcpyDeviceToHost));
     h->iter = h->h_res->iter;
+    h->dev_loop_primed = true;  // the last finalize made the next iteration's x0 call
     return MPPI_OK;
 }
 
@@ -1063,6 +1079,14 @@ extern "C" int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     return h->f64 ? closed_loop_impl<double>(h, n_iters, u0_trace, stats, (hipStream_t)stream)
                   : closed_loop_impl<float>(h, n_iters, u0_trace, stats, (hipStream_t)stream);
+}
+
+extern "C" int mppi_get_counters(mppi_handle *h, int64_t *out3) {
+    if (!h || !out3) return MPPI_ERR_BAD_ARG;
+    out3[0] = h->iter;
+    out3[1] = h->n_rollout_launches;
+    out3[2] = h->n_finalize_launches;
+    return MPPI_OK;
 }
 
 extern "C" int mppi_enable_timing(mppi_handle *h, int32_t on) {

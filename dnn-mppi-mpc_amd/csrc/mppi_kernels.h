@@ -54,6 +54,17 @@ __host__ __device__ inline int record_len(int T, int elem_bytes) {
     return 4 + ((2 * T + vw - 1) / vw) * vw;
 }
 
+// LDS of the merge code (k_merge / k_finalize), in elements of the handle's precision: the weighted noise in the
+// filter's padded layout [2 (T + W + 1)], the updated controls [2T], 64 record scales per wave and window, block
+// reductions, per-group partial sums.  Every region starts on a 16-byte boundary.
+constexpr int MERGE_THREADS = 256;
+constexpr int MERGE_MAX_RECORDS = 256;  // per window
+constexpr int MERGE_MAX_WINDOWS = 2;    // k_finalize takes up to 512 records itself (K = 16384 in the dual layout)
+__host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem, int nt = MERGE_THREADS) {
+    const size_t r4 = 3, nw = (2 * (size_t)(T + W + 1) + r4) & ~r4, nu = (2 * (size_t)T + r4) & ~r4;
+    return nw + nu + (size_t)MERGE_MAX_WINDOWS * nt + 64 + (size_t)(nt / 32) * 32 * (16 / elem);
+}
+
 template <typename R> struct KParams {
     int K, T, k_offset, noise_stream;  // noise_stream: fourth Philox counter word (of agent 0) -- kept in the first
                                        // kernel-argument fetch: the draw is the first thing a wave does

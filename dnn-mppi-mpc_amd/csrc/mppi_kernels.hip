@@ -903,9 +903,6 @@ __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rh
 // {rho, eta, eta2, pad, W[2T] padded to a 16-byte multiple}, so W is read as aligned 16-byte vectors;
 // the per-rank record of the split step uses the ABI layout {rho, eta, eta2, W[2T]} in doubles.
 // ------------------------------------------------------------------------------------------
-constexpr int MERGE_THREADS = 256;
-constexpr int MERGE_MAX_RECORDS = 256;  // per window
-constexpr int MERGE_MAX_WINDOWS = 2;    // k_finalize takes up to 512 records itself (K = 16384 in the dual layout)
 // NT threads merge 256 records: thread = (16-byte column vc = tid % 32, group grp = tid / 32), NT/32 groups of
 // 256/(NT/32) consecutive records.  NT = 256: the merge kernels' own launches; NT = 1024: the prologue of k_iter.
 template <int NT> struct MergeShape {
@@ -917,10 +914,6 @@ template <typename A> struct alignas(16) VecT { A v[16 / sizeof(A)]; };
 // LDS of the merge code.  w: the weighted noise in the filter's padded layout, [2 (T + W + 1)] (k_merge: W = 0,
 // plain); u: the updated controls [2T]; s: 64 record scales per wave; red: block reductions; part: per-group
 // partial sums.  Every region starts on a 16-byte boundary.
-__host__ __device__ inline size_t merge_lds_elems(int T, int W, size_t elem, int nt = MERGE_THREADS) {
-    const size_t r4 = 3, nw = (2 * (size_t)(T + W + 1) + r4) & ~r4, nu = (2 * (size_t)T + r4) & ~r4;
-    return nw + nu + (size_t)MERGE_MAX_WINDOWS * nt + 64 + (size_t)(nt / 32) * 32 * (16 / elem);
-}
 template <typename A, int NT = MERGE_THREADS> struct MergeLds {
     A *w, *u, *s, *red, *part;
     __device__ __forceinline__ MergeLds(char *smem, int T, int W) {
@@ -1469,17 +1462,18 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             res->iter = iter + 1;
         }
         if (f_plant) {  // next iteration's x0 call (:96-99), so the next slot needs no host input
-            A best = A(INFINITY);
+            // in f64 whatever the handle's precision, like k_set_state and the host side of mppi_step: the closed loop on
+            // the device and the same loop stepped from the host must take the same index at a near tie
+            double best = INFINITY;
             int bj = INT_MAX;
-            const A xq = (A)xn[0], yq = (A)xn[1];
             if (lane < wlen_next) {
-                const A dx = xq - cand_x, dy = yq - cand_y;
+                const double dx = xn[0] - (double)cand_x, dy = xn[1] - (double)cand_y;
                 best = dx * dx + dy * dy;
                 bj = lane;
             }
             for (int j = lane + 64; j < wlen_next; j += 64) {  // windows wider than a wave (race car: 200)
-                const A dx = xq - ref[4 * (p_now + j)], dy = yq - ref[4 * (p_now + j) + 1];
-                const A dd = dx * dx + dy * dy;
+                const double dx = xn[0] - (double)ref[4 * (p_now + j)], dy = xn[1] - (double)ref[4 * (p_now + j) + 1];
+                const double dd = dx * dx + dy * dy;
                 if (dd < best) { best = dd; bj = j; }
             }
             wv::argmin_first(best, bj);

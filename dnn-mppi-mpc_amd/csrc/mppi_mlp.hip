@@ -266,11 +266,14 @@ int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
 
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
     const size_t shmem = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (the attribute belongs to the device's copy of the code object: one process may drive several GPUs)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem, s, P, Q, (float *)partials);
 }

@@ -264,6 +264,11 @@ class Engine:
     def set_rollout_repeats(self, n):
         self._ck(self.lib.mppi_set_rollout_repeats(self._h, int(n)))
 
+    def counters(self):
+        out = (C.c_int64 * 3)()
+        self._ck(self.lib.mppi_get_counters(self._h, out))
+        return {"iterations": out[0], "rollout_launches": out[1], "finalize_launches": out[2]}
+
     def last_kernel_ms(self):
         out = (C.c_float * 4)()
         self._ck(self.lib.mppi_last_kernel_ms(self._h, out))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 2
+#define MPPI_ABI_VERSION 3
 
 typedef enum {
     MPPI_OK = 0,
@@ -261,6 +261,10 @@ int mppi_enable_timing(mppi_handle *h, int32_t on);
  * state in, same S / partial records out).  The growth of the iteration period per extra launch is that
  * kernel's launch-to-launch duration on the stream, free of any event overhead (bench.py). */
 int mppi_set_rollout_repeats(mppi_handle *h, int32_t n);
+/* Launch bookkeeping since mppi_create (host side): out3 = {iterations completed, rollout-class kernel launches
+ * (the repeats of mppi_set_rollout_repeats included), finalize launches}.  An iteration of the sequential waypoint
+ * mode may take several of each (speculation rounds); bench.py divides a measured time by these. */
+int mppi_get_counters(mppi_handle *h, int64_t *out3);
 
 #ifdef __cplusplus
 }

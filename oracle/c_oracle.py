@@ -70,16 +70,21 @@ class DiffDriveC:
         self.u_prev = np.zeros((self.T, 2))
         self.prev_way_point_idx = 0
 
-    def iteration(self, x0, eps):
+    def iteration(self, x0, eps, frozen_threads=0):
+        """``frozen_threads`` > 0: the frozen-waypoint-index variant on that many OpenMP threads (samples independent);
+        0: the reference's sequential index, one core."""
         eps = np.ascontiguousarray(eps, np.float32)
         assert eps.shape == (self.K, self.T, 2)
         x0 = np.ascontiguousarray(x0, np.float64)
         S, u0, stats, idx = np.empty(self.K), np.empty(2), np.empty(4), C.c_int(self.prev_way_point_idx)
         obs = self.obs if self.obs is not None else np.zeros(3)
-        rc = lib().oracle_diffdrive_iteration(C.byref(self.cfg), _p(self.ref, C.c_double), _p(obs, C.c_double),
-                                              _p(x0, C.c_double), _p(eps, C.c_float), _p(self.u_prev, C.c_double),
-                                              C.byref(idx), _p(S, C.c_double), _p(u0, C.c_double),
-                                              _p(stats, C.c_double))
+        args = (C.byref(self.cfg), _p(self.ref, C.c_double), _p(obs, C.c_double), _p(x0, C.c_double),
+                _p(eps, C.c_float), _p(self.u_prev, C.c_double), C.byref(idx), _p(S, C.c_double), _p(u0, C.c_double),
+                _p(stats, C.c_double))
+        if frozen_threads > 0:
+            rc = lib().oracle_diffdrive_iteration_frozen(*args, C.c_int(int(frozen_threads)))
+        else:
+            rc = lib().oracle_diffdrive_iteration(*args)
         if rc != 0:
             raise ValueError("oracle_diffdrive_iteration failed (T < 10?)")
         self.prev_way_point_idx = idx.value

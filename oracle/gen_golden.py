@@ -313,3 +313,178 @@ def gen_filters():
 
 if __name__ == "__main__" and "filters" in sys.argv[1:]:
     gen_filters()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 5: the reference's own MPPI class with `_state_transition` swapped for the residual model
+# (SURVEY.md section 8c recipe): x' = x + dt (f(x, v) + MLP([x, v])), f = the unicycle of
+# mppi_differential_drive.py:182-198, MLP = train/train_diff_mlp.py:13-36 with saved_models/mlp_diff_300x100_3l.pth
+# (weights_only=True: nothing from the file is executed).  The cost / waypoint / weight / filter / shift code that
+# runs is the reference's.  The weights travel as plain arrays (mlp_diff_300x100_3l_weights.npz): the checkpoint
+# itself does not exist on the GPU box.
+# ---------------------------------------------------------------------------------------
+
+def gen_config5():
+    import types
+
+    import torch
+    from controllers.mppi_differential_drive import MPPIAlgorithms as DD
+    from train.train_diff_mlp import MultiLayerPerceptron
+
+    sd = torch.load("/root/reference/saved_models/mlp_diff_300x100_3l.pth", map_location="cpu", weights_only=True)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "mlp_diff_300x100_3l_weights.npz"),
+                        **{k: v.numpy() for k, v in sd.items()})
+    net = MultiLayerPerceptron(5)
+    net.load_state_dict(sd)
+    net = net.double().eval()  # f64 like the NumPy controller around it (the f32 forward is recorded beside it)
+    net32 = MultiLayerPerceptron(5)
+    net32.load_state_dict(sd)
+    net32.eval()
+
+    def patched(model):
+        def _state_transition(self, x_t, v_t):  # same signature as mppi_differential_drive.py:182
+            x, y, yaw = x_t
+            speed, omega = v_t
+            z = np.array([x, y, yaw, speed, omega])
+            with torch.no_grad():
+                r = model(torch.as_tensor(z, dtype=next(model.parameters()).dtype)[None])[0].double().numpy()
+            dt = self.delta_t
+            return np.array([x + dt * (speed * np.cos(yaw) + r[0]), y + dt * (speed * np.sin(yaw) + r[1]),
+                             yaw + dt * (omega + r[2])])
+        return _state_transition
+
+    def one(name, kw, x0, seed, u_prev, idx0):
+        K, T = kw["num_samples_K"], kw["num_horizons_T"]
+        eps = philox.sample_epsilon(kw["sigma"], seed, 0, K, T)
+        caps = {}
+        for tag, model in (("", net), ("f32mlp_", net32)):
+            c = DD(**kw)
+            c._state_transition = types.MethodType(patched(model), c)
+            c.u_prev[:] = u_prev
+            c.prev_way_point_idx = idx0
+            cap = run_reference_iteration(c, np.array(x0, float), eps.astype(np.float64), "_calc_input_control")
+            caps.update({tag + k: v for k, v in cap.items() if tag == "" or k in ("S", "u_returned", "idx_after")})
+        caps.pop("sampled_traj_list")
+        caps.pop("optimal_traj")
+        save(name, kw, dict(x0=np.array(x0, float), eps_seed=np.array(seed), eps=eps if K <= 256 else None, **caps))
+
+    tt = np.arange(25)
+    one("c5_mlp_k128", dd_main_kwargs(param_exploration=0.05, visualize_optimal_traj=False, visualze_sampled_trajs=False),
+        [0.4, -0.1, -0.35], 71, np.stack([1.2 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1), 2)
+    tt = np.arange(50)
+    one("c5_mlp_k1024", dd_main_kwargs(num_samples_K=1024, num_horizons_T=50, param_exploration=0.1,
+                                       visualize_optimal_traj=False, visualze_sampled_trajs=False),
+        [1.0, -0.6, -0.45], 72, np.stack([1.5 + 0.5 * np.sin(0.2 * tt), -0.05 + 0.1 * np.cos(0.1 * tt)], axis=1), 6)
+
+
+if __name__ == "__main__" and "c5" in sys.argv[1:]:
+    gen_config5()
+
+
+# ---------------------------------------------------------------------------------------
+# The race-car driver's plant: Vehicle.update (models/vehicle.py:85-114) in the loop of
+# controllers/mppi_race_car.py:259-281 -- (a) exactly as that `__main__` runs it (the controller is fed
+# ref_path[i], the vehicle integrates the returned controls beside it), (b) closed: the controller is fed the
+# vehicle's state (what `mppi_run_closed_loop` does on the device).
+# ---------------------------------------------------------------------------------------
+
+def gen_vehicle():
+    from controllers.mppi_race_car import MPPIRacecarController as RC
+    from models.vehicle import Vehicle
+    kw = dict(delta_t=0.05, wheel_base=2.5, max_steer_abs=0.523, max_accel_abs=2.0, horizon_step_T=20,
+              number_of_samples_K=192, param_exploration=0.01, param_lambda=50.0, param_alpha=1.0,
+              sigma=np.array([[0.5, 0.0], [0.0, 0.1]]), stage_cost_weight=np.array([50.0, 50.0, 1.0, 20.0]),
+              terminal_cost_weight=np.array([50.0, 50.0, 1.0, 20.0]), visualize_optimal_traj=False,
+              visualze_sampled_trajs=False)
+    # :224-234, cast as the driver does (:267).  An open arc of that circle: on the closed one the 200-candidate search
+    # of the x0 call jumps to the last waypoint (= the first one) as soon as the car has left the start, and the
+    # controller raises (:63-65) in its second closed-loop iteration
+    path = RC().generate_simple_trajectory(100, 10.0).astype(np.float32)[:80]
+    n_it, seed = 12, 81
+    rec = {}
+    for mode in ("driver", "closed"):
+        c = RC(**dict(kw, ref_path=path))
+        veh = Vehicle(ref_path=path[:, :2], visualize=False)
+        veh.reset(init_state=np.array(path[0], dtype=np.float64))
+        xs, us, vs, idx = [], [], [veh.get_state()], []
+        for i in range(n_it):
+            state = path[i] if mode == "driver" else veh.get_state()
+            eps = philox.sample_epsilon(kw["sigma"], seed, i, 192, 20)
+            cap = run_reference_iteration(c, state, eps, "_calc_control_input")
+            veh.update(u=cap["u0_returned"], delta_t=c.delta_t, append_frame=False)
+            xs.append(np.array(state, np.float64))
+            us.append(cap["u0_returned"])
+            idx.append(cap["idx_after"])
+            vs.append(veh.get_state())
+        rec.update({mode + "_x0": np.array(xs), mode + "_u0": np.array(us), mode + "_vehicle": np.array(vs),
+                    mode + "_idx_after": np.array(idx), mode + "_u_final": c.u_prev.copy()})
+    save("plant_rc_vehicle", kw, dict(eps_seed=np.array(seed), ref_path=path, **rec))
+
+
+if __name__ == "__main__" and "vehicle" in sys.argv[1:]:
+    gen_vehicle()
+
+
+# ---------------------------------------------------------------------------------------
+# controllers/mppi_differential_drive_torch.py run on the CPU (f32 torch): beta = lambda (:187-190), no clamp in
+# the rollout (:128), terminal yaw wrap (:231), conv1d filter (:252-263).  Its `_state_transition` (:196-209) adds
+# into VIEWS of its argument, so the first step of every sample advances the shared `x0` -- a defect, not a
+# behaviour to keep: the fixture is taken with that one aliasing removed (the argument is
+# cloned before the reference's own function body runs); every line of arithmetic is the reference's.
+# ---------------------------------------------------------------------------------------
+
+def gen_dd_torch():
+    import torch
+    from controllers.mppi_differential_drive_torch import MPPIAlgorithms as DDT
+
+    orig = DDT._state_transition
+
+    def no_alias(self, x_t, v_t):
+        return orig(self, x_t.clone(), v_t)
+
+    def one(name, x0, seed, u_prev, idx0, **over):
+        cx = np.linspace(0.0, 10.0, 100)
+        cy = np.linspace(0.0, -5.0, 100)
+        cyaw = np.arctan2(-5.0, 10.0) * np.ones(100)
+        kw = dict(delta_t=0.1, ref_path=np.array([cx, cy, cyaw]).T, max_speed=5.0, max_omega=3.14, num_samples_K=96,
+                  num_horizons_T=20, param_exploration=0.05, param_lambda=1.0, param_alpha=0.2,
+                  sigma=np.array([[0.1, 0.0], [0.0, 0.01]]), stage_cost_weight=np.array([5.0, 5.0, 10.0]),
+                  terminal_cost_weight=np.array([5.0, 5.0, 10.0]), visualize_optimal_traj=False,
+                  visualize_sampled_traj=False)
+        kw.update(over)
+        f = lambda v: torch.tensor(v, dtype=torch.float32)
+        c = DDT(delta_t=f(kw["delta_t"]), ref_path=f(kw["ref_path"]), max_speed=f(kw["max_speed"]),
+                max_omega=f(kw["max_omega"]), num_samples_K=kw["num_samples_K"], num_horizons_T=kw["num_horizons_T"],
+                param_exploration=f(kw["param_exploration"]), param_lambda=f(kw["param_lambda"]),
+                param_alpha=f(kw["param_alpha"]), sigma=f(kw["sigma"]), stage_cost_weight=f(kw["stage_cost_weight"]),
+                terminal_cost_weight=f(kw["terminal_cost_weight"]), visualize_optimal_traj=kw["visualize_optimal_traj"],
+                visualize_sampled_traj=kw["visualize_sampled_traj"])
+        c._state_transition = no_alias.__get__(c)
+        K, T = kw["num_samples_K"], kw["num_horizons_T"]
+        eps = philox.sample_epsilon(kw["sigma"], seed, 0, K, T)
+        c._calc_epsilon = lambda *a, **k: torch.tensor(eps)
+        c.u_prev[:] = f(u_prev)
+        c.prev_way_point_idx = idx0
+        log = {}
+        cw, mf = c._compute_weight, c._moving_average_filter
+        c._compute_weight = lambda S: (log.__setitem__("S", S.clone().numpy()), cw(S))[1]
+        c._moving_average_filter = lambda xx, window_size: (log.__setitem__("w_eps_raw", xx.clone().numpy()),
+                                                            mf(xx=xx, window_size=window_size))[1]
+        x0t = f(x0)
+        u0, u, _, _ = c._calc_input_control(x0t)
+        assert np.allclose(x0t.numpy(), np.asarray(x0, np.float32)), "x0 aliasing was not removed"
+        save(name, kw, dict(x0=np.array(x0, float), eps=eps, eps_seed=np.array(seed), u_prev_in=np.array(u_prev, float),
+                            idx_before=np.array(idx0), S=log["S"], w_eps_raw=log["w_eps_raw"],
+                            u_returned=c.u_prev.clone().numpy(), u0_returned=c.u_prev[0].clone().numpy(),
+                            idx_after=np.array(int(c.prev_way_point_idx))))
+
+    tt = np.arange(20)
+    one("ddtorch_default", [0.0, 0.0, 0.0], 91, np.zeros((20, 2)), 0)
+    one("ddtorch_unclamped_wrap", [1.0, -0.4, -0.9], 92,
+        np.stack([1.5 + 0.5 * np.sin(0.3 * tt), 0.2 * np.cos(0.2 * tt)], axis=1), 5, max_speed=0.6, max_omega=0.1,
+        param_lambda=2.0, param_exploration=0.1, visualize_sampled_traj=True)
+
+
+if __name__ == "__main__" and "ddtorch" in sys.argv[1:]:
+    gen_dd_torch()

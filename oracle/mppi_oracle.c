@@ -148,6 +148,77 @@ int oracle_diffdrive_iteration(const oracle_cfg *c, const double *ref, const dou
     return 0;
 }
 
+/*
+ * The same iteration with the FROZEN waypoint index (every call searches the window at the x0 index, the engine's
+ * MPPI_WAYPOINT_FROZEN): samples are independent then, so the K loop runs on all host cores (OpenMP).  This is the
+ * all-core CPU figure of bench.py's `cpu_baseline`; the reference's own sequential index
+ * (above) cannot be parallelised over samples.  Checked against the NumPy restatement in tests/test_oracle_c.py.
+ */
+int oracle_diffdrive_iteration_frozen(const oracle_cfg *c, const double *ref, const double *obs, const double *x0,
+                                      const float *eps, double *u_prev, int *idx, double *S, double *u0_out,
+                                      double *stats, int n_threads) {
+    const int K = c->K, T = c->T;
+    if (T < 10) return -1;
+    double *u = u_prev;
+    double *w_eps = (double *)calloc((size_t)4 * T, sizeof(double)), *filt = w_eps + 2 * T;
+    double *wgt = (double *)malloc(sizeof(double) * K);
+    int p0 = dd_nearest(ref, c->n_ref, *idx, x0[0], x0[1]);
+    const int path_end = p0 >= c->n_ref - 1;
+    if (path_end) p0 = c->n_ref - 1;
+    const double gamma = c->param_lambda * (1.0 - c->param_alpha);
+    const double det = c->sigma[0] * c->sigma[3] - c->sigma[1] * c->sigma[2];
+    const double si[4] = {c->sigma[3] / det, -c->sigma[1] / det, -c->sigma[2] / det, c->sigma[0] / det};
+    const double thr = (1.0 - c->param_exploration) * K, dt = c->delta_t;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int k = 0; k < K; ++k) {
+        double x = x0[0], y = x0[1], yaw = x0[2], s = 0.0;
+        int p = p0;
+        for (int t = 0; t < T; ++t) {
+            double e0 = eps[((size_t)k * T + t) * 2], e1 = eps[((size_t)k * T + t) * 2 + 1];
+            double v0 = (double)k < thr ? u[2 * t] + e0 : e0, v1 = (double)k < thr ? u[2 * t + 1] + e1 : e1;
+            v0 = clampd(v0, -c->u_max0, c->u_max0);
+            v1 = clampd(v1, -c->u_max1, c->u_max1);
+            double nx = x + v0 * cos(yaw) * dt, ny = y + v0 * sin(yaw) * dt;
+            yaw = yaw + v1 * dt;
+            x = nx;
+            y = ny;
+            p = dd_nearest(ref, c->n_ref, p0, x, y); /* frozen: always from the x0 index */
+            double q0 = u[2 * t] * si[0] + u[2 * t + 1] * si[2], q1 = u[2 * t] * si[1] + u[2 * t + 1] * si[3];
+            s = dd_state_cost(c, c->stage_w, ref, obs, p, x, y, yaw) + gamma * (q0 * v0 + q1 * v1);
+        }
+        S[k] = s + dd_state_cost(c, c->term_w, ref, obs, p, x, y, yaw);
+    }
+    *idx = p0;
+    double rho = S[0], eta = 0.0;
+    for (int k = 1; k < K; ++k) rho = S[k] < rho ? S[k] : rho;
+    for (int k = 0; k < K; ++k) { wgt[k] = exp(-(1.0 / c->param_exploration) * (S[k] - rho)); eta += wgt[k]; }
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int t = 0; t < T; ++t) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int k = 0; k < K; ++k) {
+            a0 += wgt[k] / eta * eps[((size_t)k * T + t) * 2];
+            a1 += wgt[k] / eta * eps[((size_t)k * T + t) * 2 + 1];
+        }
+        w_eps[2 * t] = a0;
+        w_eps[2 * t + 1] = a1;
+    }
+    dd_moving_average(w_eps, filt, T);
+    for (int i = 0; i < 2 * T; ++i) u[i] += filt[i];
+    if (c->clamp_u_after_update)
+        for (int t = 0; t < T; ++t) {
+            u[2 * t] = clampd(u[2 * t], -c->u_max0, c->u_max0);
+            u[2 * t + 1] = clampd(u[2 * t + 1], -c->u_max1, c->u_max1);
+        }
+    memmove(u, u + 2, sizeof(double) * 2 * (T - 1));
+    u0_out[0] = u[0];
+    u0_out[1] = u[1];
+    if (stats) { stats[0] = rho; stats[1] = eta; stats[2] = p0; stats[3] = path_end; }
+    free(w_eps);
+    free(wgt);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- race car -- */
 
 #define TWO_PI_F 6.2831855f /* float32(2.0*np.pi), mppi_race_car.py:141 under NEP 50 */

@@ -136,11 +136,20 @@ class DiffDriveOracle:
     # wrapped into [0, 2 pi) (:239) -- set both on an instance to restate it (confirmed by diffing
     # the two sources; the file itself cannot run here, cupy is absent)
     WRAP_YAW_TERMINAL = False
+    # mppi_differential_drive_torch.py: the rollout does not clamp (:128), the softmin rate is lambda itself
+    # (:187-190), the terminal yaw is wrapped (:231) and the moving average is the conv1d form (:252-263) -- set
+    # CLAMP_ROLLOUT = False, BETA_IS_LAMBDA = True, WRAP_YAW_TERMINAL = True, FILTER = moving_average_torch
+    # (pinned by tests/golden/ddtorch_*.npz: that file run on the CPU with its x0 aliasing removed)
+    CLAMP_ROLLOUT = True
+    BETA_IS_LAMBDA = False
+    FILTER = None  # None: moving_average_diffdrive
 
     def __init__(self, delta_t, ref_path, max_speed, max_omega, num_samples_K, num_horizons_T,
                  param_exploration, param_lambda, param_alpha, sigma, stage_cost_weight,
                  terminal_cost_weight, obstacle_circles=None, safety_margin_rate=None,
-                 visualize_optimal_traj=True, visualze_sampled_trajs=True):
+                 visualize_optimal_traj=True, visualze_sampled_trajs=True, visualize_sampled_traj=None):
+        if visualize_sampled_traj is not None:  # the torch file's spelling (:63-64)
+            visualze_sampled_trajs = visualize_sampled_traj
         self.delta_t = float(delta_t)
         self.ref_path = np.asarray(ref_path, dtype=np.float64)
         self.max_speed = float(max_speed)
@@ -203,7 +212,8 @@ class DiffDriveOracle:
     def compute_weight(self, S):
         """`_compute_weight` :167-180 (sequential eta)."""
         rho = S.min()
-        e = np.exp(-(1.0 / self.param_exploration) * (S - rho))
+        beta = self.param_lambda if self.BETA_IS_LAMBDA else 1.0 / self.param_exploration
+        e = np.exp(-beta * (S - rho))
         eta = sequential_sum(e)
         return (1 / eta) * e
 
@@ -228,7 +238,9 @@ class DiffDriveOracle:
         # :116-121
         thr = exploit_threshold(self.param_exploration, K)
         exploit = (np.arange(K) < thr)[:, None, None]
-        v = self.clamp(np.where(exploit, u[None] + eps, eps))
+        v = np.where(exploit, u[None] + eps, eps)
+        if self.CLAMP_ROLLOUT:
+            v = self.clamp(v)
         X = self.rollout(x0, v)
 
         # :124,:126 -- waypoint state threaded through K*(T+1) calls, k-major
@@ -260,7 +272,7 @@ class DiffDriveOracle:
         out["w"] = wgt
         w_eps = sequential_sum(wgt[:, None, None] * eps, axis=0)  # :132-135
         out["w_eps_raw"] = w_eps
-        w_eps = moving_average_diffdrive(w_eps, 10)  # :138
+        w_eps = moving_average_diffdrive(w_eps, 10) if self.FILTER is None else type(self).FILTER(w_eps, 10)  # :138
         out["w_eps_filtered"] = w_eps
         u = u + w_eps  # :141
         out["u_pre_clamp"] = u.copy()
@@ -466,6 +478,16 @@ def diffdrive_plant_step(state, u, dt):
     """`DifferentialDrive.update_state` mppi_differential_drive.py:33-40."""
     x, y, yaw = state
     return np.array([x + u[0] * np.cos(yaw) * dt, y + u[0] * np.sin(yaw) * dt, yaw + u[1] * dt])
+
+
+def racecar_plant_step(state, u, dt, wheel_base=2.5, max_steer_abs=0.523, max_accel_abs=2.0):
+    """`Vehicle.update` models/vehicle.py:85-114: the kinematic bicycle with the controls clipped first; f64 state
+    (pinned by tests/golden/plant_rc_vehicle.npz)."""
+    x, y, yaw, v = np.asarray(state, np.float64)
+    steer = np.clip(u[0], -max_steer_abs, max_steer_abs)
+    accel = np.clip(u[1], -max_accel_abs, max_accel_abs)
+    return np.array([x + v * np.cos(yaw) * dt, y + v * np.sin(yaw) * dt, yaw + v / wheel_base * np.tan(steer) * dt,
+                     v + accel * dt])
 
 
 def generate_point_trajectory(start_point, end_point, num_points=100):

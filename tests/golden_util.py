@@ -50,3 +50,9 @@ def make_racecar_oracle(fx, raise_at_path_end=False):
         o.u_prev[:] = fx["u_prev_in"]
         o.prev_waypoints_idx = int(fx["idx_before"])
     return o
+
+
+def mlp_weights():
+    """saved_models/mlp_diff_300x100_3l.pth as plain arrays (the checkpoint itself stays in the build container)."""
+    z = np.load(os.path.join(GOLDEN, "mlp_diff_300x100_3l_weights.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}

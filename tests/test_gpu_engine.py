@@ -583,3 +583,116 @@ def test_batched_agents_equal_separate_handles(monkeypatch, dual, model):
     with pytest.raises(pkg.MppiError) as ex:  # the sequential waypoint index cannot be batched
         pkg.Engine(K=K, n_agents=2, **dict(base, waypoint_mode=capi.WAYPOINT_SEQUENTIAL))
     assert ex.value.code == capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", gu.names("c5_"))
+def test_config5_checkpoint_against_patched_reference(name):
+    """BASELINE config 5 pinned through the reference itself (tests/golden/c5_*.npz: the reference's MPPIAlgorithms with
+    `_state_transition` = x + dt (f + MLP), MLP = its MultiLayerPerceptron with saved_models/mlp_diff_300x100_3l.pth;
+    oracle/gen_golden.py gen_config5).  The weights travel as plain arrays.  Tolerance: north star, u within 1e-4 RMSE;
+    waypoint index equal; S to 1e-3 (f32 matrix cores through 3 x 512-wide layers and T recurrent steps)."""
+    import dnn_mppi_mpc_amd as pkg
+    fx = gu.load(name)
+    c = pkg.MPPIAlgorithms(**fx["meta"], learned_dynamics=gu.mlp_weights())
+    c.u_prev[:] = fx["u_prev_in"]
+    c.prev_way_point_idx = int(fx["idx_before"])
+    eps = gu.eps_of(fx)
+    c._calc_epsilon = lambda *a, **k: eps
+    u0, u, _, _ = c._calc_input_control(fx["x0"])
+    np.testing.assert_allclose(c.sample_costs(), fx["S"], rtol=1e-3, atol=1e-3)
+    assert rmse(u, fx["u_returned"]) <= 1e-4
+    assert rmse(u0, fx["u0_returned"]) <= 1e-4
+    assert c.prev_way_point_idx == int(fx["idx_after"])
+
+
+def test_config5_full_size_k32768_subset_against_oracle():
+    """BASELINE config 5 at its full size (K = 32768, T = 50, the real checkpoint) with the frozen waypoint index, in
+    which samples are independent: the costs of a strided 1024-sample subset against the f64 NumPy restatement, then
+    size-independent properties on all K -- the softmin weights sum to one, the update equals the weighted noise of
+    the costs the kernel reported, and a constant shift of every cost leaves it unchanged (by construction of rho)."""
+    import dnn_mppi_mpc_amd as pkg
+    K, T, seed = 32768, 50, 555
+    w = gu.mlp_weights()
+    kw = dd_kwargs(K, T, param_exploration=0.05)
+    tt = np.arange(T)
+    u_in = np.stack([1.2 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1)
+    x0 = np.array([0.4, -0.1, -0.35])
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode="frozen", seed=seed)
+    c.u_prev[:] = u_in
+    u = c._calc_input_control(x0)[1].copy()  # in-kernel Philox, iteration 0
+    S = c.sample_costs()
+    assert S.shape == (K,) and np.isfinite(S).all()
+    # --- subset against the restatement
+    eps = philox.sample_epsilon(kw["sigma"], seed, 0, K, T)
+    sub = np.arange(0, K, 32)
+    o = mppi_oracle.DiffDriveMlpOracle(**dict(kw, num_samples_K=sub.size), mlp_weights=w)
+    p0 = o.nearest_waypoint(x0[0], x0[1], 0)
+    exploit = (sub < mppi_oracle.exploit_threshold(kw["param_exploration"], K))[:, None, None]
+    v = o.clamp(np.where(exploit, u_in[None] + eps[sub], eps[sub].astype(np.float64)))
+    X = o.rollout(x0, v)
+    R, win = o.ref_path, o.ref_path[p0:p0 + 20]
+    xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+    i = p0 + np.argmin((xT[:, None] - win[:, 0]) ** 2 + (yT[:, None] - win[:, 1]) ** 2, axis=1)
+    ws, wt = o.stage_cost_weight, o.terminal_cost_weight
+    q = u_in[T - 1] @ np.linalg.inv(o.Sigma)
+    S_ref = ((ws[0] + wt[0]) * (xT - R[i, 0]) ** 2 + (ws[1] + wt[1]) * (yT - R[i, 1]) ** 2
+             + (ws[2] + wt[2]) * (yawT - R[i, 2]) ** 2 + o.param_gamma * (q[0] * v[:, -1, 0] + q[1] * v[:, -1, 1]))
+    np.testing.assert_allclose(S[sub], S_ref, rtol=1e-3, atol=1e-3)
+    # --- all K: weights and the update from the kernel's own costs (f64 on the host)
+    beta = 1.0 / kw["param_exploration"]
+    e = np.exp(-beta * (S - S.min()))
+    wk = e / e.sum()
+    assert abs(c._compute_weight().sum() - 1.0) < 1e-9
+    np.testing.assert_allclose(c._compute_weight(), wk, rtol=1e-5, atol=1e-12)
+    w_eps = mppi_oracle.moving_average_diffdrive(np.einsum("k,ktd->td", wk, eps.astype(np.float64)), 10)
+    un = u_in + w_eps
+    expect = np.vstack([un[1:], un[-1:]])
+    assert rmse(u, expect) <= 1e-4
+    assert c.last_stats.ess > 1.0
+
+
+def test_f32_device_closed_loop_matches_host_loop_over_a_traversal():
+    """The bench's timed path is the f32 closed loop on the device.  Step it one iteration at a time and give a second
+    controller, stepped from the host (`_calc_input_control`), the device's state before each iteration: same kernels,
+    same noise -- the returned control, the waypoint index after every iteration (the whole traversal of the path and
+    the first iterations at its end) and the nominal sequence must be identical.  The x0 nearest-waypoint call is the
+    one piece with two implementations (finalize kernel / host side of mppi_step): both run in f64."""
+    import dnn_mppi_mpc_amd as pkg
+    kw = dd_kwargs(2048, 40)
+    a = pkg.MPPIAlgorithms(**kw, precision="f32", seed=77)
+    b = pkg.MPPIAlgorithms(**kw, precision="f32", seed=77)
+    a._engine.set_state(np.zeros(3))
+    moved = 0
+    for it in range(45):
+        x = a._engine.get_state()
+        tr, st = a._engine.run_closed_loop(1, trace=True)
+        u0 = b._calc_input_control(x)[0].copy()
+        np.testing.assert_array_equal(tr[0], u0)
+        assert st.idx_after == b.prev_way_point_idx, it
+        assert st.idx_start == b.last_stats.idx_start, it
+        moved += st.idx_after != st.idx_start
+        np.testing.assert_array_equal(a._engine.get_u_prev(), b.u_prev)
+    assert moved >= 10 and b.prev_way_point_idx == 99  # the run did traverse the path
+
+
+def test_racecar_closed_loop_does_not_depend_on_how_it_is_chunked():
+    """run(a) + run(b) == run(a + b) with the frozen waypoint index on a path that passes close to itself (the
+    lemniscate's crossing): the finalize kernel has already made the next iteration's x0 call, a second one at the start
+    of the next mppi_run_closed_loop would search from its result instead of prev_waypoints_idx."""
+    import dnn_mppi_mpc_amd as pkg
+    lem = mppi_oracle.generate_lemniscate_racecar(400, 10.0)[:300]
+    kw = dict(ref_path=lem, horizon_step_T=20, number_of_samples_K=512, visualize_optimal_traj=False,
+              visualze_sampled_trajs=False)
+    whole = pkg.MPPIRacecarController(**kw, seed=3)
+    parts = pkg.MPPIRacecarController(**kw, seed=3)
+    for c in (whole, parts):
+        c._engine.set_state(lem[0].astype(np.float64))
+    n = 60
+    tr_w, st_w = whole._engine.run_closed_loop(n, trace=True)
+    tr_p = []
+    for m in (1, 7, 20, 1, 31):
+        tr, st_p = parts._engine.run_closed_loop(m, trace=True)
+        tr_p.append(tr)
+    np.testing.assert_array_equal(np.concatenate(tr_p), tr_w)
+    np.testing.assert_array_equal(parts._engine.get_state(), whole._engine.get_state())
+    assert st_p.idx_after == st_w.idx_after and st_w.idx_after > 0

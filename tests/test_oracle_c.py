@@ -52,3 +52,35 @@ def test_diffdrive_rejects_short_horizon():
     o = c_oracle.DiffDriveC(**meta)
     with pytest.raises(ValueError):
         o.iteration(fx["x0"], np.zeros((o.K, 9, 2), np.float32))
+
+
+def test_c_diffdrive_frozen_index_openmp_variant():
+    """The all-core CPU baseline of bench.py (frozen waypoint index, OpenMP over the samples) against NumPy: with the
+    index frozen at the x0 call's waypoint every sample searches the same window, so S is a plain function of x_T."""
+    from oracle import c_oracle, mppi_oracle
+    fx = gu.load("dd_c2_k4096_moderate")
+    eps = gu.eps_of(fx)
+    m = fx["meta"]
+    o = c_oracle.DiffDriveC(**m)
+    o.u_prev[:] = fx["u_prev_in"]
+    o.prev_way_point_idx = int(fx["idx_before"])
+    got = o.iteration(fx["x0"], eps, frozen_threads=4)
+    n = mppi_oracle.DiffDriveOracle(**m)
+    u, x0 = fx["u_prev_in"], fx["x0"]
+    p0 = n.nearest_waypoint(x0[0], x0[1], int(fx["idx_before"]))
+    K, T = n.K, n.T
+    v = n.clamp(np.where((np.arange(K) < mppi_oracle.exploit_threshold(m["param_exploration"], K))[:, None, None],
+                         u[None] + eps, eps.astype(np.float64)))
+    X = n.rollout(x0, v)
+    R, win = n.ref_path, n.ref_path[p0:p0 + 20]
+    xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+    i = p0 + np.argmin((xT[:, None] - win[:, 0]) ** 2 + (yT[:, None] - win[:, 1]) ** 2, axis=1)
+    ws, wt = n.stage_cost_weight, n.terminal_cost_weight
+    q = u[T - 1] @ np.linalg.inv(n.Sigma)
+    S = ((ws[0] + wt[0]) * (xT - R[i, 0]) ** 2 + (ws[1] + wt[1]) * (yT - R[i, 1]) ** 2
+         + (ws[2] + wt[2]) * (yawT - R[i, 2]) ** 2 + n.param_gamma * (q[0] * v[:, -1, 0] + q[1] * v[:, -1, 1]))
+    np.testing.assert_allclose(got["S"], S, rtol=1e-10, atol=1e-10)
+    assert got["idx_after"] == p0
+    wk = np.exp(-(S - S.min()) / m["param_exploration"])
+    un = u + mppi_oracle.moving_average_diffdrive(np.einsum("k,ktd->td", wk / wk.sum(), eps.astype(np.float64)), 10)
+    np.testing.assert_allclose(got["u_returned"], np.vstack([un[1:], un[-1:]]), rtol=1e-8, atol=1e-11)

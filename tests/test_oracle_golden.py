@@ -105,3 +105,69 @@ def test_moving_average_filters_match_reference(T):
     np.testing.assert_allclose(mppi_oracle.moving_average_torch(xx, 10), fx[f"rctorch_T{T}"], rtol=1e-5, atol=1e-7)
     # what the torch form is: the NumPy race-car filter delayed by window // 2 rows
     np.testing.assert_allclose(fx[f"rctorch_T{T}"][5:], fx[f"rc_T{T}"][:T - 5], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", gu.names("ddtorch_"))
+def test_diffdrive_torch_variant_matches_reference(name):
+    """controllers/mppi_differential_drive_torch.py run on the CPU in f32 (its x0 aliasing removed, see
+    oracle/gen_golden.py): beta = lambda, no clamp in the rollout, terminal yaw wrap, conv1d filter.  The f64
+    restatement with those four switches agrees to f32 rounding."""
+    fx = gu.load(name)
+
+    class TorchVariant(mppi_oracle.DiffDriveOracle):
+        CLAMP_ROLLOUT, BETA_IS_LAMBDA, WRAP_YAW_TERMINAL = False, True, True
+        FILTER = staticmethod(mppi_oracle.moving_average_torch)
+
+    o = TorchVariant(**fx["meta"])
+    o.u_prev[:] = fx["u_prev_in"]
+    o.prev_way_point_idx = int(fx["idx_before"])
+    out = o.iteration(fx["x0"], fx["eps"].astype(np.float64))
+    np.testing.assert_allclose(out["S"], fx["S"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out["w_eps_raw"], fx["w_eps_raw"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(out["u_returned"], fx["u_returned"], rtol=1e-4, atol=5e-6)
+    assert out["idx_after"] == int(fx["idx_after"])
+    plain = gu.make_diffdrive_oracle(fx).iteration(fx["x0"], fx["eps"].astype(np.float64))
+    assert not np.allclose(plain["u_returned"], fx["u_returned"], atol=1e-3)  # the switches matter
+
+
+@pytest.mark.parametrize("name", gu.names("c5_"))
+def test_config5_residual_mlp_matches_patched_reference(name):
+    """BASELINE config 5 pinned through the reference itself: its MPPIAlgorithms with `_state_transition` replaced by
+    x + dt (f + MLP) (the reference's MultiLayerPerceptron with saved_models/mlp_diff_300x100_3l.pth, f64), see
+    oracle/gen_golden.py gen_config5.  The restatement = DiffDriveMlpOracle with the same weights."""
+    fx = gu.load(name)
+    w = gu.mlp_weights()
+    o = mppi_oracle.DiffDriveMlpOracle(**fx["meta"], mlp_weights=w)
+    o.u_prev[:] = fx["u_prev_in"]
+    o.prev_way_point_idx = int(fx["idx_before"])
+    out = o.iteration(fx["x0"], gu.eps_of(fx).astype(np.float64))
+    np.testing.assert_allclose(out["S"], fx["S"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(out["u_returned"], fx["u_returned"], rtol=1e-8, atol=1e-12)
+    assert out["idx_after"] == int(fx["idx_after"])
+    # the f32 forward of the same network (what the engine's matrix-core path computes in) stays within the budget
+    assert np.sqrt(np.mean((fx["f32mlp_u_returned"] - fx["u_returned"]) ** 2)) < 1e-5
+    assert int(fx["f32mlp_idx_after"]) == int(fx["idx_after"])
+
+
+def test_racecar_plant_matches_vehicle_update():
+    """`Vehicle.update` (models/vehicle.py:85-114) as the race-car driver runs it (mppi_race_car.py:259-281): the
+    controller is fed ref_path[i], the vehicle integrates the returned controls; and the closed loop (controller fed
+    the vehicle's state)."""
+    fx = gu.load("plant_rc_vehicle")
+    m = fx["meta"]
+    for mode in ("driver", "closed"):
+        veh, u0 = fx[mode + "_vehicle"], fx[mode + "_u0"]
+        for i in range(u0.shape[0]):
+            nxt = mppi_oracle.racecar_plant_step(veh[i], u0[i], m["delta_t"], m["wheel_base"], m["max_steer_abs"],
+                                                 m["max_accel_abs"])
+            np.testing.assert_allclose(nxt, veh[i + 1], rtol=1e-12, atol=1e-12)
+    # the whole closed loop through the restatement
+    o = mppi_oracle.RaceCarOracle(ref_path=fx["ref_path"], **m)
+    state = fx["closed_vehicle"][0]
+    for i in range(fx["closed_u0"].shape[0]):
+        np.testing.assert_allclose(state, fx["closed_x0"][i], rtol=1e-4, atol=1e-4)
+        out = o.iteration(state, gu.eps_of(fx, i))
+        np.testing.assert_allclose(out["u0_returned"], fx["closed_u0"][i], rtol=1e-3, atol=2e-5)
+        assert out["idx_after"] == int(fx["closed_idx_after"][i])
+        state = mppi_oracle.racecar_plant_step(state, out["u0_returned"], m["delta_t"], m["wheel_base"],
+                                               m["max_steer_abs"], m["max_accel_abs"])
