@@ -84,6 +84,19 @@ def cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one (a GPU box gives each GPU's job a
+    share of the host, e.g. 16 of 256), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("MPPI_BENCH_CPU_THREADS", "16")))  # (16 = the pool's CPU share per GPU)
+
+
 def cpu_baseline(budget_s=10.0, budget_all_s=6.0):
     """The C restatement of the reference loop (config 2, closed loop, eps pre-generated): the reference's own sequential
     waypoint index on ONE host core (it cannot be parallelised over samples), and beside it the frozen-index variant
@@ -108,7 +121,7 @@ def cpu_baseline(budget_s=10.0, budget_all_s=6.0):
         return n, spent
 
     n1, s1 = run(budget_s, 0)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     na, sa = run(budget_all_s, cores)
     return {"value": K_SAMPLES * HORIZON * n1 / s1, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
             "cpu_model": cpu_model(),

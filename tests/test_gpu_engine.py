@@ -648,7 +648,7 @@ def test_config5_full_size_k32768_subset_against_oracle():
     un = u_in + w_eps
     expect = np.vstack([un[1:], un[-1:]])
     assert rmse(u, expect) <= 1e-4
-    assert c.last_stats.ess > 1.0
+    assert 1.0 <= c.last_stats.ess <= K and abs(c.last_stats.ess - 1.0 / np.sum(wk ** 2)) <= 1e-3 * c.last_stats.ess
 
 
 def test_f32_device_closed_loop_matches_host_loop_over_a_traversal():
