@@ -27,6 +27,10 @@ struct mppi_handle {
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
     void *d_heads = nullptr, *d_heads2 = nullptr;  // compact {rho, eta, eta2, 0} of d_partials / d_partials2
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
+    // one-launch resolution of the sequential waypoint index (HYP_R in mppi_kernels.h)
+    bool hyp = false;
+    void *d_hyp_rec = nullptr, *d_hyp_heads = nullptr, *d_hyp_S = nullptr;
+    unsigned char *d_hyp_map = nullptr, *d_hyp_q = nullptr;
     std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
     StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
     long long seq = 0;
@@ -215,6 +219,25 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_heads2, 32 * n2)) != hipSuccess) return fail(e, "hipMalloc(heads2)");
     if ((e = hipMemset(h->d_heads, 0, 32 * n1)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_heads2, 0, 32 * n2)) != hipSuccess) return fail(e, "hipMemset");
+    // The sequential index in one launch: the fused one-sample-per-wave layout with one 64-step chunk, the reference's
+    // 20-candidate window, `S[k] =`, one agent, at most 256 workgroups (K <= 4096).  Anything else keeps the speculation
+    // rounds alone (they also serve as this path's fallback).  MPPI_NO_HYP=1 switches it off for A/B runs.
+    h->hyp = h->fused && (h->layout & LAYOUT_KIND) == LAYOUT_FUSED && c.T <= 64 && c.model == MPPI_MODEL_DIFFDRIVE &&
+             c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && c.search_window == HYP_WINDOW &&
+             c.n_agents == 1 && h->n_part <= HYP_MAX_BLOCKS && !getenv("MPPI_NO_HYP");
+    if (h->hyp) {
+        const size_t nrec = (size_t)HYP_MAX_BLOCKS * HYP_R;
+        if ((e = hipMalloc(&h->d_hyp_rec, rec_bytes * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp records)");
+        if ((e = hipMalloc(&h->d_hyp_heads, 32 * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp heads)");
+        if ((e = hipMalloc(&h->d_hyp_S, sizeof(double) * 16 * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp costs)");
+        if ((e = hipMalloc((void **)&h->d_hyp_map, nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp maps)");
+        if ((e = hipMalloc((void **)&h->d_hyp_q, HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMalloc(hyp entries)");
+        if ((e = hipMemset(h->d_hyp_rec, 0, rec_bytes * nrec)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipMemset(h->d_hyp_heads, 0, 32 * nrec)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipMemset(h->d_hyp_S, 0, sizeof(double) * 16 * nrec)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipMemset(h->d_hyp_map, 0, nrec)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipMemset(h->d_hyp_q, 0, HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMemset");
+    }
     h->res_bytes = (h->res_bytes + 15) & ~(size_t)15;  // (the agents' results are stored back to back)
     if ((e = hipMalloc((void **)&h->d_st, B * sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
     if ((e = hipMalloc((void **)&h->d_res, B * h->res_bytes)) != hipSuccess) return fail(e, "hipMalloc(result)");
@@ -248,7 +271,8 @@ extern "C" int mppi_destroy(mppi_handle *h) {
     hipSetDevice(h->cfg.device);
     if (h->xbuf) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
-                    h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2};
+                    h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2, h->d_hyp_rec, h->d_hyp_heads,
+                    h->d_hyp_S, h->d_hyp_map, h->d_hyp_q};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_res) hipHostFree(h->h_res);
@@ -477,6 +501,13 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.n_agents = h->B;
     P.layout = h->layout;
     P.heads = (R *)h->d_heads;
+    // the kernels that can resolve the sequential index in one launch -- while that index can still move: once it sits
+    // on the last waypoint (it only grows) every search window holds one candidate and the lean kernels serve
+    P.hyp = h->hyp && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
+    P.hyp_rec = (R *)h->d_hyp_rec;
+    P.hyp_heads = (R *)h->d_hyp_heads;
+    P.hyp_map = h->d_hyp_map;
+    P.hyp_S = (R *)h->d_hyp_S;
     return P;
 }
 
@@ -519,6 +550,14 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.n_agents = h->B;
     F.res_stride = h->res_bytes;
     F.u0_trace = nullptr;
+    F.hyp = h->hyp && partials == h->d_partials && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
+    F.hyp_blocks = h->n_part;
+    F.hyp_rec = h->d_hyp_rec;
+    F.hyp_heads = h->d_hyp_heads;
+    F.hyp_S = h->d_hyp_S;
+    F.hyp_map = h->d_hyp_map;
+    F.hyp_q = h->d_hyp_q;
+    F.S = h->d_S;
     return F;
 }
 
@@ -698,6 +737,7 @@ static int step_impl(mppi_handle *h, const double *x0, const float *eps, double 
     if (by_args) {
         P.use_args = F.use_args = 1;
         P.c_arg = F.c_arg = host_x0_call(h, x0);
+        P.hyp = F.hyp = h->hyp && P.c_arg < h->n_ref - 1;  // (a window of one candidate: nothing can move)
         for (int i = 0; i < 4; ++i) P.x0_arg[i] = F.x0_arg[i] = x0[i];
     } else {
         launch_set_state<R>(P, x0, s);
@@ -853,10 +893,23 @@ extern "C" int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, m
     return MPPI_OK;
 }
 
+// S[K] on the device: an iteration that ended in the one-launch resolution of the waypoint index leaves the costs per
+// workgroup and entry index (StepResult::costs_hyp); pick the realised ones
+static int materialise_costs(mppi_handle *h) {
+    if (!h->hyp || !h->h_res->costs_hyp) return MPPI_OK;
+    if (h->f64) launch_gather_costs<double>((const double *)h->d_hyp_S, h->d_hyp_q, (double *)h->d_S, h->cfg.K, nullptr);
+    else launch_gather_costs<float>((const float *)h->d_hyp_S, h->d_hyp_q, (float *)h->d_S, h->cfg.K, nullptr);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipDeviceSynchronize());
+    h->h_res->costs_hyp = 0;
+    return MPPI_OK;
+}
+
 extern "C" int mppi_get_costs(mppi_handle *h, double *S) {
     if (!h || !S) return MPPI_ERR_BAD_ARG;
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
+    if (int rc = materialise_costs(h)) return rc;
     return download_real(h, S, h->d_S, (size_t)h->B * h->cfg.K);  // [n_agents][K]
 }
 
@@ -864,6 +917,8 @@ extern "C" int mppi_get_weights(mppi_handle *h, double *w) {
     if (!h || !w) return MPPI_ERR_BAD_ARG;
     SINGLE_AGENT_ONLY(h, "mppi_get_weights");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
+    HIPCHECK(h, hipDeviceSynchronize());
+    if (int rc = materialise_costs(h)) return rc;
     if (!h->d_w) HIPCHECK(h, hipMalloc((void **)&h->d_w, sizeof(double) * h->cfg.K));
     if (h->f64) {
         KParams<double> P = make_params<double>(h, nullptr);
@@ -1041,8 +1096,11 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     h->dev_loop_primed = false;
     long long done = h->iter;
     int guard = 0;
+    // While the HYPK kernels are in use the host looks in on the waypoint index after 32, 64, 128 ... slots: at the end
+    // of the path (the reference driver's run reaches it after some 23 of its 1000 iterations) the lean kernels take over
+    long long batch = P.hyp ? 32 : (1LL << 62);
     while (done < target) {
-        const long long todo = target - done;
+        const long long todo = target - done < batch ? target - done : batch;
         for (long long i = 0; i < todo; ++i) launch_slot<R>(h, P, F, s);
         HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, (size_t)h->B * h->res_bytes, hipMemcpyDeviceToHost, s));
         HIPCHECK(h, hipStreamSynchronize(s));
@@ -1054,7 +1112,15 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         }
         if (h->h_res->status == STATUS_PATH_END || h->h_res->status == STATUS_EXCHANGE_FAILED) break;
         done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
-        if (++guard > h->cfg.K + 8) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
+        if (P.hyp) {
+            if (h->B == 1 && h->h_res->idx_after >= h->n_ref - 1) {
+                P.hyp = F.hyp = 0;
+                batch = 1LL << 62;
+            } else {
+                batch *= 2;
+            }
+        }
+        if (++guard > h->cfg.K + 64) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
     }
     h->last_eps = nullptr;
     h->last_philox = true;

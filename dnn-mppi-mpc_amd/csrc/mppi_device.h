@@ -121,6 +121,67 @@ template <typename R> __device__ __forceinline__ int window_len(int window, int 
     return rem < window ? rem : window;
 }
 
+// ---- one-launch resolution of the sequential index (HYP_R in mppi_kernels.h) -------------------------------------
+// The HYP_CAND candidates ref[c .. c+34] as pairs (see RefPair); candidates past the end of the path are far-away
+// points that can never win, so every window [q, q+20) is truncated at the path's end like the reference's slice
+// (mppi_differential_drive.py:206-208).
+template <typename R>
+__device__ __forceinline__ void hyp_stage_window(RefPair<R> *sh, const R *__restrict__ ref, int c, int n_ref, int tid) {
+    if (tid < (HYP_CAND + 1) / 2) {
+        const int j0 = c + 2 * tid, j1 = j0 + 1;
+        const bool h0 = j0 < n_ref, h1 = j1 < n_ref && 2 * tid + 1 < HYP_CAND;
+        RefPair<R> r;
+        r.x0 = h0 ? ref[4 * j0] : R(1e30);
+        r.y0 = h0 ? ref[4 * j0 + 1] : R(1e30);
+        r.x1 = h1 ? ref[4 * j1] : R(1e30);
+        r.y1 = h1 ? ref[4 * j1 + 1] : R(1e30);
+        sh[tid] = r;
+    }
+}
+
+// This lane's call as a table: g(q) = offset of the first nearest candidate in [q, q+20), q = 0 .. HYP_R-1 (one byte
+// each), for the position (x, y).  Sliding-window first minimum in one pass over the 35 candidates: running first
+// minimum from the left over candidates 20..34 (a window's part beyond 19), from the right over 19..0 (its part up to
+// 19; `<=` hands ties to the smaller index), and per q the smaller of the two with ties to the left part.
+struct alignas(16) HypTable { unsigned w[HYP_R / 4]; };
+template <typename R> __device__ __forceinline__ HypTable hyp_table(const RefPair<R> *win, R x, R y) {
+    static_assert(HYP_R == 16 && HYP_WINDOW == 20 && HYP_CAND == 35, "hyp_table is written for 16 entries and a 20-candidate window");
+    auto dist = [&](int i) {
+        const RefPair<R> r = win[i >> 1];
+        const R dx = x - ((i & 1) ? r.x1 : r.x0), dy = y - ((i & 1) ? r.y1 : r.y0);
+        return dx * dx + dy * dy;
+    };
+    R pv[HYP_R - 1];
+    int pi[HYP_R - 1];
+    {
+        R best = R(INFINITY);
+        int bi = HYP_WINDOW;
+#pragma unroll
+        for (int i = HYP_WINDOW; i < HYP_CAND; ++i) {
+            const R d = dist(i);
+            if (d < best) { best = d; bi = i; }
+            pv[i - HYP_WINDOW] = best;
+            pi[i - HYP_WINDOW] = bi;
+        }
+    }
+    HypTable g;
+#pragma unroll
+    for (int q = 0; q < HYP_R / 4; ++q) g.w[q] = 0u;
+    R sv = R(INFINITY);
+    int si = HYP_WINDOW - 1;
+#pragma unroll
+    for (int i = HYP_WINDOW - 1; i >= 0; --i) {
+        const R d = dist(i);
+        if (d <= sv) { sv = d; si = i; }
+        if (i < HYP_R) {
+            int gi = si;
+            if (i >= 1 && pv[i - 1] < sv) gi = pi[i - 1];  // the window [i, i+19] reaches candidate 20 + (i-1)
+            g.w[i >> 2] |= (unsigned)gi << (8 * (i & 3));
+        }
+    }
+    return g;
+}
+
 // collision indicator of one state (mppi_differential_drive_obs.py:301-313,
 // mppi_race_car_obstacle.py:241-274)
 // The obstacle table lives in registers: lane m holds circle m {centre, squared radius} (one vector load issued at

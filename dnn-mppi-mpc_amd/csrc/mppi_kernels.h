@@ -21,6 +21,17 @@ __host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
     return sizeof(long long) * XCHG_MAX_RANKS + sizeof(double) * (size_t)nranks * xchg_rec_len(T);
 }
 
+// Sequential waypoint index resolved in ONE launch (mppi_differential_drive.py:201-249: one `prev_way_point_idx`
+// threaded through all K (T+1) cost calls in k-major order).  Every call is a map p -> g(p) = first nearest waypoint
+// in [p, p+20); a sample is the composition of its T+1 maps, a workgroup of its 16 samples', an iteration of its
+// workgroups'.  The index only moves forward and, per iteration, by a handful of waypoints, so the maps are tabulated
+// on the HYP_R entry indices c .. c+HYP_R-1 (c = the x0 call's index): the rollout launch leaves, per workgroup, the
+// map and one softmin record PER ENTRY INDEX; the finalize kernel composes the 256 maps (a chain of table lookups)
+// and merges the records of the realised entries.  A chain that leaves the table (HYP_OVF) falls back to the
+// speculation rounds from that workgroup on, so the result is exact either way.
+constexpr int HYP_R = 16, HYP_WINDOW = 20, HYP_CAND = HYP_R + HYP_WINDOW - 1, HYP_OVF = 255;
+constexpr int HYP_MAX_BLOCKS = 256;  // workgroups whose maps one finalize block composes
+
 // Controller state that lives on the device (so closed loops need no host round trip).
 struct DevState {
     double x0[4];      // observed state of the current iteration
@@ -38,7 +49,8 @@ struct DevState {
 // What the host reads back after a step (followed by 2*T doubles: the returned u).
 struct StepResult {
     int status, k_next, c_next, idx_start;
-    int idx_after, path_end, rounds, pad;
+    int idx_after, path_end, rounds;
+    int costs_hyp;  // the iteration ended in the one-launch resolution: S[k] = hyp_S[k / 16][hyp_q[k / 16]][k % 16]
     long long iter;
     double rho, eta, ess;
     double u0[2];
@@ -93,6 +105,12 @@ template <typename R> struct KParams {
     double x0_arg[4];
     // several agents per launch (blockIdx.y): agent a's u / S / pout / state / records / heads follow agent a-1's
     int n_agents, layout;   // layout: rollout_layout() of the handle (host side only)
+    // one-launch resolution of the sequential index (see HYP_R): per workgroup b and entry index q
+    int hyp;                // the handle qualifies (fused layout, T <= 64, window 20, `S[k] =`, one agent, <= 256 workgroups)
+    R *hyp_rec;             // [blocks][HYP_R][record_len]  softmin record of workgroup b entered at c + q
+    R *hyp_heads;           // [blocks][HYP_R][4]
+    unsigned char *hyp_map; // [blocks][HYP_R]               index offset the workgroup leaves behind (HYP_OVF: left the table)
+    R *hyp_S;               // [blocks][HYP_R][16]           the samples' costs under that entry
 };
 
 struct FinalizeParams {
@@ -126,6 +144,12 @@ struct FinalizeParams {
     // several agents per launch (blockIdx.y), see KParams
     int slots, n_agents;
     size_t res_stride;       // bytes between two agents' StepResult (+ returned u)
+    // one-launch resolution of the sequential index (see HYP_R / KParams)
+    int hyp, hyp_blocks;
+    const void *hyp_rec, *hyp_heads, *hyp_S;
+    const unsigned char *hyp_map;
+    unsigned char *hyp_q;    // [blocks] the entry offset each workgroup was realised with (kept for mppi_get_costs)
+    void *S;                 // [K] handle precision: costs of the samples resolved before a chain left the table
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights
@@ -166,6 +190,9 @@ void launch_merge(const void *recs, const void *heads, int n, int group, int T, 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f64, hipStream_t s);
 // exchange self-test: one flag round over the peers, no records
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s);
+// S[k] of an iteration that ended in the one-launch resolution (StepResult::costs_hyp)
+template <typename R>
+void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
                    float *eps_out, hipStream_t s, unsigned stream_word = 0);

@@ -133,9 +133,9 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
         }
     }
 
-    // steps [64 ch, 64 ch + 64) of the horizon; returns the noise it used
-    __device__ __forceinline__ void chunk(int ch, float &e0, float &e1) {
-        const R *__restrict__ ref = P.ref;
+    // S2-S3 of steps [64 ch, 64 ch + 64): this lane's controls and the state after its step (returns the noise it used)
+    struct Step { R x, y, yaw, vel, u0, u1, v0, v1; bool act; };
+    __device__ __forceinline__ Step dynamics(int ch, float &e0, float &e1) {
         const int t = ch * 64 + lane;
         const bool act = t < P.T;
         STAMP(8);
@@ -180,8 +180,16 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
         cy = wv::read_lane(y, 63);
         cyaw = wv::read_lane(yaw, 63);
         if (MODEL == MODEL_RACE) cvel = wv::read_lane(vel, 63);
-
         STAMP(10);
+        return Step{x, y, yaw, vel, u0, u1, v0, v1, act};
+    }
+
+    // steps [64 ch, 64 ch + 64) of the horizon; returns the noise it used
+    __device__ __forceinline__ void chunk(int ch, float &e0, float &e1) {
+        const R *__restrict__ ref = P.ref;
+        const Step sp = dynamics(ch, e0, e1);
+        const R x = sp.x, y = sp.y, yaw = sp.yaw, vel = sp.vel, u0 = sp.u0, u1 = sp.u1, v0 = sp.v0, v1 = sp.v1;
+        const bool act = sp.act;
         // ---- waypoint index of every call in this chunk ----------------------------------
         int my_idx;
         if (!P.sequential) {
@@ -351,10 +359,138 @@ template <int N> __device__ __forceinline__ void publish_first_mover(const int *
     if (m != NO_TRIGGER) atomicMin(first_k, m);
 }
 
+// ------------------------------------------------------------------------------------------
+// The sequential waypoint index in ONE launch (HYP_R in mppi_kernels.h; mppi_differential_drive.py:201-249).
+// Every wave tabulates its sample's T+1 calls as maps on the HYP_R entry offsets, composes them (lanes over the entry
+// offset, a chain of LDS byte reads split over four lane groups), and prices the sample under every entry; the
+// workgroup chains its 16 samples the same way and leaves, PER ENTRY OFFSET Q, its map value, the samples' costs and a
+// softmin record.  k_finalize composes the workgroups' maps and merges the records of the realised entries.
+// `S[k] =` semantics only (:124): the cost needs the index of the last stage call and of the terminal call.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {  // a wave reads what its own lanes have just written to LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename R, bool OBS, bool PLAIN>
+__device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &sv) {
+    __shared__ RefPair<R> sh_win[(HYP_CAND + 1) / 2];
+    __shared__ __attribute__((aligned(16))) unsigned char sh_g[FUSED_WAVES][64][HYP_R];
+    __shared__ unsigned char sh_seg[FUSED_WAVES][4][HYP_R];
+    __shared__ unsigned char sh_M[FUSED_WAVES][HYP_R];
+    __shared__ R sh_Sq[FUSED_WAVES][HYP_R];  // sample w priced with ITSELF entered at offset q
+    __shared__ R sh_SQ[FUSED_WAVES][HYP_R];  // sample w priced with the WORKGROUP entered at offset Q
+    __shared__ R sh_e[FUSED_WAVES][HYP_R];
+    __shared__ R sh_eps[FUSED_WAVES][128];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, q = lane & (HYP_R - 1);
+    const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
+    const bool valid = k < P.K;
+    const int c = sv.c, T = P.T;
+    hyp_stage_window(sh_win, P.ref, c, P.n_ref, (int)threadIdx.x);
+    const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
+    __syncthreads();
+    float e0 = 0.f, e1 = 0.f;
+    int M = q;                // the sample's map at entry offset q (an absent sample: identity)
+    R Sq = R(INFINITY);       // its cost entered at q
+    if (valid) {
+        Rollout<R, MODEL_DIFF, OBS, PLAIN> r(P, sv, k, lane, nullptr, obs, 0);
+        const auto sp = r.dynamics(0, e0, e1);
+        const HypTable g = hyp_table(sh_win, sp.x, sp.y);
+        *reinterpret_cast<HypTable *>(&sh_g[wid][lane][0]) = g;
+        wave_lds_sync();
+        // compose the T stage calls: lane group s chains calls [s Ts, (s+1) Ts) from every entry offset, then the
+        // four partial maps are chained
+        const int seg = lane >> 4, Ts = (T + 3) >> 2, tb = seg * Ts, te = min(T, tb + Ts);
+        int p = q;
+        for (int t = tb; t < te; ++t) p = p < HYP_R ? (int)sh_g[wid][t][p] : HYP_OVF;
+        sh_seg[wid][seg][q] = (unsigned char)p;
+        wave_lds_sync();
+        p = q;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) p = p < HYP_R ? (int)sh_seg[wid][s4][p] : HYP_OVF;
+        const int a_stage = p;                                                      // the last stage call's index (:228)
+        const int a_term = p < HYP_R ? (int)sh_g[wid][T - 1][p] : HYP_OVF;          // the terminal call: same state (:244)
+        // the state after the last step and its control cost, held by lane T-1
+        const int ll = r.lane_last;
+        const R xT = wv::read_lane(sp.x, ll), yT = wv::read_lane(sp.y, ll), yawT = wv::read_lane(sp.yaw, ll);
+        const R ctrl = (sp.u0 * P.sinv[0] + sp.u1 * P.sinv[2]) * sp.v0 + (sp.u0 * P.sinv[1] + sp.u1 * P.sinv[3]) * sp.v1;  // :124
+        const R ctrlT = wv::read_lane(ctrl, ll);
+        const bool hit_lane = OBS ? collided<false>(P, sp.x, sp.y, sp.yaw, obs) : false;
+        const bool hitT = OBS ? ((__ballot(hit_lane) >> ll) & 1ull) != 0ull : false;
+        if (a_stage < HYP_R && a_term < HYP_R) {
+            R st_c = tracking_cost<R, MODEL_DIFF>(P, P.ws, r.wrap_stage(), c + a_stage, xT, yT, yawT, R(0));
+            if (hitT) st_c += P.penalty;
+            const R stage = st_c + P.gamma * ctrlT;
+            R term = tracking_cost<R, MODEL_DIFF>(P, P.wt, r.wrap_term(), c + a_term, xT, yT, yawT, R(0));
+            if (hitT) term += P.penalty;
+            Sq = stage + term;
+            M = a_term;
+        } else {
+            M = HYP_OVF;  // the index leaves the table: this entry is resolved by the speculation rounds instead
+        }
+    }
+    if (lane < HYP_R) {
+        sh_M[wid][lane] = (unsigned char)M;
+        sh_Sq[wid][lane] = Sq;
+    }
+    sh_eps[wid][2 * lane] = (R)e0;
+    sh_eps[wid][2 * lane + 1] = (R)e1;
+    __syncthreads();
+    // the offset this sample is entered at when the WORKGROUP is entered at Q = q: through the samples before it
+    int ent = q;
+    for (int j = 0; j < wid; ++j) ent = ent < HYP_R ? (int)sh_M[j][ent] : HYP_OVF;
+    const R SQ = ent < HYP_R ? sh_Sq[wid][ent] : R(INFINITY);
+    const int after = ent < HYP_R ? (int)sh_M[wid][ent] : HYP_OVF;  // (the last wave's: what the workgroup leaves)
+    if (lane < HYP_R) sh_SQ[wid][lane] = SQ;
+    __syncthreads();
+    R rho = sh_SQ[0][q];
+#pragma unroll
+    for (int w = 1; w < FUSED_WAVES; ++w) rho = fmin(rho, sh_SQ[w][q]);
+    const R e = SQ < R(INFINITY) ? mf::exp_(-P.beta * (SQ - rho)) : R(0);  // :175
+    if (lane < HYP_R) sh_e[wid][lane] = e;
+    __syncthreads();
+    const size_t b = blockIdx.x;
+    const int rlen = record_len(T, (int)sizeof(R));
+    {   // W_b(Q)[i] = sum_k e_k(Q) eps[k, i] (:132-135): thread = (column i, a pair of entry offsets)
+        const int i = threadIdx.x & 127, Q0 = 2 * ((int)threadIdx.x >> 7);
+        if (i < 2 * T) {
+            R a0 = 0, a1 = 0;
+#pragma unroll
+            for (int w = 0; w < FUSED_WAVES; ++w) {
+                const R ev = sh_eps[w][i];
+                a0 += sh_e[w][Q0] * ev;
+                a1 += sh_e[w][Q0 + 1] * ev;
+            }
+            P.hyp_rec[(b * HYP_R + Q0) * rlen + 4 + i] = a0;
+            P.hyp_rec[(b * HYP_R + Q0 + 1) * rlen + 4 + i] = a1;
+        }
+    }
+    if (lane < HYP_R) P.hyp_S[(b * HYP_R + lane) * FUSED_WAVES + wid] = SQ;
+    if (wid == FUSED_WAVES - 1 && lane < HYP_R) {
+        R eta = 0, eta2 = 0;
+#pragma unroll
+        for (int w = 0; w < FUSED_WAVES; ++w) {
+            const R ew = sh_e[w][lane];
+            eta += ew;
+            eta2 += ew * ew;
+        }
+        R *out = P.hyp_rec + (b * HYP_R + lane) * rlen;
+        out[0] = rho;
+        out[1] = eta;
+        out[2] = eta2;
+        *reinterpret_cast<VecT4<R> *>(P.hyp_heads + 4 * (b * HYP_R + lane)) = VecT4<R>{rho, eta, eta2, R(0)};
+        P.hyp_map[b * HYP_R + lane] = (unsigned char)after;
+    }
+}
+
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
 // SPEC: 0 general, 1 no obstacles, 2 no obstacles + the PLAIN switches (see Rollout)
-template <typename R, int MODEL, int NCH, bool MULTI, int SPEC>
+// HYPK: the instantiation that can resolve the sequential index in one launch (fused_hyp).  A separate instantiation,
+// picked by the host while the waypoint index can still move (KParams::hyp): carrying that code costs the lean kernel
+// 0.17 us per launch in registers and LDS (A/B on one box), and at the end of the path nothing moves any more.
+template <typename R, int MODEL, int NCH, bool MULTI, int SPEC, bool HYPK = false>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevState *st_pre, const KParams<R> P,
                                                                     R *__restrict__ partials) {
     constexpr bool OBS = SPEC == 0, PLAIN = SPEC == 2;
@@ -371,9 +507,13 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     const int k_start = sv.k_start;
     STAMP(1);
     const bool valid = k < P.K;
+    const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
+    if (HYPK) {
+        // the first round of an iteration whose waypoint index can move: every entry index at once (fused_hyp)
+        if (sv.round == 0 && wlen0 > 1) return fused_hyp<R, OBS, PLAIN>(P, sv);
+    }
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
-    const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
     // Both waypoint modes search the window at c first.  A window of ONE candidate (the robot holds the end of the
     // path) leaves nothing to search or to move: no staging and no barrier behind its loads then (0.7 us per launch
     // at config 2).
@@ -882,6 +1022,14 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
     }
 }
 
+// S[k] of an iteration that ended in the one-launch resolution of the sequential index (fused_hyp): workgroup b was
+// realised with entry offset hyp_q[b]
+template <typename R>
+__global__ void k_gather_costs(const R *__restrict__ hyp_S, const unsigned char *__restrict__ hyp_q, R *__restrict__ S, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) S[k] = hyp_S[((size_t)(k >> 4) * HYP_R + hyp_q[k >> 4]) * 16 + (k & 15)];
+}
+
 // normalised weights of the last iteration (`_compute_weight` :167-180), for inspection
 template <typename R>
 __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rho, double eta, double *w) {
@@ -968,12 +1116,17 @@ template <typename A, int NT = MERGE_THREADS, int NWIN = 1> struct MergeRegs {
     A hr[4 * NWIN], he[4 * NWIN], he2[4 * NWIN];  // heads of records 256 win + lane + {0, 64, 128, 192}
 };
 
+// `sel` (LDS, one byte per record): record b is entry sel[b] of workgroup b's HYP_R records (fused_hyp) -- the stride
+// between workgroups is HYP_R records then
 template <typename A, int NT, int NWIN>
-__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT, NWIN> &m) {
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT, NWIN> &m,
+                                                 const unsigned char *sel = nullptr) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 4 * NWIN; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
-        const VecT4<A> hd = *reinterpret_cast<const VecT4<A> *>(heads + 4 * (size_t)(lane + 64 * i));
+        const int b = lane + 64 * i;
+        const size_t r = sel ? (size_t)b * HYP_R + min((int)sel[b], HYP_R - 1) : (size_t)b;
+        const VecT4<A> hd = *reinterpret_cast<const VecT4<A> *>(heads + 4 * r);
         m.hr[i] = hd.x;
         m.he[i] = hd.y;
         m.he2[i] = hd.z;
@@ -981,13 +1134,24 @@ __device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, Me
 }
 
 template <typename A, int NT, int NWIN>
-__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT, NWIN> &m) {
+__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT, NWIN> &m,
+                                                const unsigned char *sel = nullptr) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ;
     const int tid = threadIdx.x, vc = tid & 31, grp = tid >> 5;
     const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
     const int nvc = (2 * T + VW - 1) / VW;  // 16-byte columns of W
     const char *base = reinterpret_cast<const char *>(recs);
-    const unsigned off0 = (unsigned)(grp * MAXJ) * rbytes + (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+    const unsigned col = (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
+    if (sel) {  // (NWIN == 1: the one-launch resolution serves up to HYP_MAX_BLOCKS = 256 workgroups)
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int b = grp * MAXJ + j;
+            const unsigned r = (unsigned)b * HYP_R + (unsigned)min((int)sel[b], HYP_R - 1);
+            m.w[0][j] = *reinterpret_cast<const VecT<A> *>(base + (size_t)r * rbytes + col);
+        }
+        return;
+    }
+    const unsigned off0 = (unsigned)(grp * MAXJ) * rbytes + col;
 #pragma unroll
     for (int win = 0; win < NWIN; ++win)
 #pragma unroll
@@ -999,7 +1163,7 @@ __device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int 
 template <typename A, int NT, int NWIN, typename Store>
 __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta,
                                               MergeRegs<A, NT, NWIN> &m, A *sh_s, A *sh_part, A &rho, A &eta, A &eta2,
-                                              Store store) {
+                                              Store store, const unsigned char *sel = nullptr) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ, GROUPS = MergeShape<NT>::GROUPS;
     using V = VecT<A>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1054,7 +1218,7 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
         if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT, NWIN>(recs, T, vt + 1, m);  // T > 64 only
+        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT, NWIN>(recs, T, vt + 1, m, sel);  // T > 64 (f64: 32) only
         for (int e = tid; e < 32 * VW; e += NT) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
@@ -1193,7 +1357,7 @@ __global__ __launch_bounds__(64) void k_exchange_probe(const FinalizeParams F, i
 // PLAIN: the closed loop of the diff-drive NumPy controller on one GPU (sequential index, its moving average, the plant
 // on the device, no host arguments, no trace) -- the run-time switches below are constants then (0.15 us per iteration at
 // config 2, A/B on one box); launch_finalize picks it when every condition holds.
-template <typename A, int MODE, int NT, int NWIN, bool PLAIN = false>
+template <typename A, int MODE, int NT, int NWIN, bool PLAIN = false, bool HYPK = false>
 __device__ __forceinline__ void finalize_body(const void *partials_pre, const void *heads_pre, const DevState *st_pre,
                                               const void *u_pre, int T_pre, const FinalizeParams &F, char *smem,
                                               int agent) {
@@ -1280,9 +1444,86 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         if (tid == 0) { res->status = STATUS_EXCHANGE_FAILED; res->iter = iter; }
         return leave();
     }
-    // --- sequential-waypoint speculation: did a sample move the index? ---------------------
+    // --- the sequential index resolved in this launch: compose the workgroups' maps (fused_hyp) -----------------
     int c_final = c_state;
-    if (f_sequential && fk != NO_TRIGGER) {
+    bool hyp_done = false;
+    const unsigned char *sel = nullptr;  // != null: the records to merge are the realised entries of the HYP_R per workgroup
+    if (HYPK) {  // (launched with the HYPK rollout kernel: the same condition there)
+        static_assert(!HYPK || (MODE == 0 && NWIN == 1 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
+        if (round == 0 && min(F.window, F.n_ref - c_state) > 1) {
+            unsigned char *sh_map = reinterpret_cast<unsigned char *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));
+            unsigned char *sh_G = sh_map + HYP_MAX_BLOCKS * HYP_R;  // [16][HYP_R]: groups of 16 workgroups
+            unsigned char *sh_ent = sh_G + 16 * HYP_R;              // [16] offset each group is entered at
+            unsigned char *sh_q = sh_ent + 16;                      // [256] offset each workgroup is entered at
+            int *sh_i = reinterpret_cast<int *>(sh_q + HYP_MAX_BLOCKS);  // {first workgroup that leaves the table, final offset}
+            const int nb = F.hyp_blocks;
+            *reinterpret_cast<uint4 *>(sh_map + HYP_R * tid) = *reinterpret_cast<const uint4 *>(F.hyp_map + HYP_R * tid);
+            if (tid == 0) sh_i[0] = INT_MAX;
+            __syncthreads();
+            {   // every group of 16 workgroups as one map: thread = (group, entry offset), 16 chained byte reads
+                const int g = tid >> 4, Q = tid & 15;
+                int p = Q;
+                for (int j = 0; j < 16; ++j) {
+                    const int b = 16 * g + j;
+                    if (b < nb) p = p < HYP_R ? (int)sh_map[HYP_R * b + p] : HYP_OVF;
+                }
+                sh_G[HYP_R * g + Q] = (unsigned char)p;
+            }
+            __syncthreads();
+            if (tid < 16) {  // the offset group `tid` is entered at: the iteration enters at 0 (the x0 call's index)
+                int p = 0;
+                for (int j = 0; j < tid; ++j) p = p < HYP_R ? (int)sh_G[HYP_R * j + p] : HYP_OVF;
+                sh_ent[tid] = (unsigned char)p;
+            }
+            __syncthreads();
+            if (tid < 16) {  // and every workgroup of the group
+                int p = sh_ent[tid], first = INT_MAX;
+                for (int j = 0; j < 16; ++j) {
+                    const int b = 16 * tid + j;
+                    sh_q[b] = (unsigned char)p;
+                    if (b < nb) {
+                        const int nxt = p < HYP_R ? (int)sh_map[HYP_R * b + p] : HYP_OVF;
+                        if (p < HYP_R && nxt == HYP_OVF && first == INT_MAX) first = b;
+                        p = nxt;
+                    }
+                }
+                if (first != INT_MAX) atomicMin(&sh_i[0], first);
+                if (tid == 15) sh_i[1] = p;
+            }
+            __syncthreads();
+            const int b_ovf = sh_i[0];
+            if (b_ovf != INT_MAX) {
+                // workgroup b_ovf's chain left the table from its (known) entry: everything before it is final -- keep
+                // those costs -- and the speculation rounds take over from there with that entry as the index
+                const A *hS = reinterpret_cast<const A *>(F.hyp_S);
+                A *S = reinterpret_cast<A *>(F.S);
+                for (int k = tid; k < 16 * b_ovf; k += NT) {
+                    const int b = k >> 4;
+                    S[k] = hS[((size_t)b * HYP_R + sh_q[b]) * 16 + (k & 15)];
+                }
+                nx.k_start = 16 * b_ovf;
+                nx.c = c_state + sh_q[b_ovf];
+                nx.round = round + 1;
+                if (tid == 0) {
+                    res->status = STATUS_NEED_ROUND;
+                    res->k_next = nx.k_start;
+                    res->c_next = nx.c;
+                    res->rounds = round + 1;
+                    res->iter = iter;
+                }
+                return leave();
+            }
+            c_final = c_state + sh_i[1];
+            hyp_done = true;
+            sel = sh_q;
+            if (tid < nb) F.hyp_q[tid] = sh_q[tid];  // (mppi_get_costs picks the samples' costs with it)
+            merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(F.hyp_heads), mr, sel);
+            merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(F.hyp_rec), T_pre, 0, mr, sel);
+            partials = F.hyp_rec;
+        }
+    }
+    // --- sequential-waypoint speculation: did a sample move the index? ---------------------
+    if (!hyp_done && f_sequential && fk != NO_TRIGGER) {
         const int c_new = pout[fk];
         if (fk + 1 < F.K) {  // samples after fk were evaluated from a stale index: another round
             nx.k_start = fk + 1;
@@ -1330,7 +1571,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
                      store_w);
     } else if (!XCHG) {
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
-                                   eta, eta2, store_w);
+                                   eta, eta2, store_w, sel);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
@@ -1455,6 +1696,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             res->idx_after = p_now;
             res->path_end = path_end;
             res->rounds = round + 1;
+            res->costs_hyp = hyp_done ? 1 : 0;
             res->rho = (double)rho; res->eta = (double)eta; res->ess = (double)(eta * eta / eta2);
             res->u0[0] = (double)u0a; res->u0[1] = (double)u0b;
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];
@@ -1490,7 +1732,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     STAMP(21);
 }
 
-template <typename A, int MODE, int NWIN, bool MULTI, bool PLAIN = false>
+template <typename A, int MODE, int NWIN, bool MULTI, bool PLAIN = false, bool HYPK = false>
 __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials_pre, const void *heads_pre,
                                                             const DevState *st_pre, const void *u_pre, int T_pre,
                                                             const FinalizeParams F) {
@@ -1503,7 +1745,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_finalize(const void *partials
                                                     st_pre + a, reinterpret_cast<const A *>(u_pre) + (size_t)a * 2 * T_pre,
                                                     T_pre, F, smem, a);
     } else {
-        finalize_body<A, MODE, MERGE_THREADS, NWIN, PLAIN>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, 0);
+        finalize_body<A, MODE, MERGE_THREADS, NWIN, PLAIN, HYPK>(partials_pre, heads_pre, st_pre, u_pre, T_pre, F, smem, 0);
     }
 }
 
@@ -1671,7 +1913,13 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
             const dim3 block(64 * FUSED_WAVES);
 #define MPPI_LAUNCH_FUSED(NCH_, SPEC_) \
     hipLaunchKernelGGL((k_rollout_fused<R, MODEL, NCH_, MULTI, SPEC_>), grid, block, 0, s, P.st, P, partials)
-            if (P.T <= 64) {
+#define MPPI_LAUNCH_FUSED_HYP(SPEC_) \
+    hipLaunchKernelGGL((k_rollout_fused<R, MODEL_DIFF, 1, false, SPEC_, true>), grid, block, 0, s, P.st, P, partials)
+            if (P.hyp && P.T <= 64 && !MULTI && MODEL == MODEL_DIFF) {
+                if (spec == 2) MPPI_LAUNCH_FUSED_HYP(2);
+                else if (spec == 1) MPPI_LAUNCH_FUSED_HYP(1);
+                else MPPI_LAUNCH_FUSED_HYP(0);
+            } else if (P.T <= 64) {
                 if (spec == 2) MPPI_LAUNCH_FUSED(1, 2);
                 else if (spec == 1) MPPI_LAUNCH_FUSED(1, 1);
                 else MPPI_LAUNCH_FUSED(1, 0);
@@ -1681,6 +1929,7 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
                 else MPPI_LAUNCH_FUSED(2, 0);
             }
 #undef MPPI_LAUNCH_FUSED
+#undef MPPI_LAUNCH_FUSED_HYP
         }
     }
 }
@@ -1716,7 +1965,8 @@ void launch_merge(const void *recs, const void *heads, int n, int group, int T, 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_recs, hipStream_t s) {
     // (+ the staging area of the peer-to-peer exchange; merge_lds_elems is a multiple of 4 elements: 16-byte aligned)
     const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R)) +
-                       (F.x_nranks > 1 ? sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(F.T) : 0);
+                       (F.x_nranks > 1 ? sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(F.T) : 0) +
+                       (F.hyp ? (size_t)HYP_MAX_BLOCKS * HYP_R + 16 * HYP_R + 16 + HYP_MAX_BLOCKS + 16 : 0);
     const DevState *st = F.st;
     const bool two = F.n_part > MERGE_MAX_RECORDS;  // (at most MERGE_MAX_WINDOWS * 256: the caller merges above that)
     const bool multi = !abi_recs && F.x_nranks <= 1 && F.n_agents > 1;  // one workgroup per agent
@@ -1728,16 +1978,26 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_rec
     else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2, false); else MPPI_FIN(2, 1, false); }
     else if (multi) { if (two) MPPI_FIN(0, 2, true); else MPPI_FIN(0, 1, true); }
     else if (two) MPPI_FIN(0, 2, false);
-    else if (F.sequential && F.plant && !F.use_args && !F.raise_at_path_end && !F.clamp_u && F.model == MODEL_DIFF &&
-             !F.u0_trace && F.filter_mode == FILTER_DIFF)
-        hipLaunchKernelGGL((k_finalize<R, 0, 1, false, true>), grid, dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,
-                           (const void *)F.u, F.T, F);
-    else MPPI_FIN(0, 1, false);
+    else {
+        const bool plain = F.sequential && F.plant && !F.use_args && !F.raise_at_path_end && !F.clamp_u && F.model == MODEL_DIFF &&
+                           !F.u0_trace && F.filter_mode == FILTER_DIFF;
+#define MPPI_FIN_SINGLE(PLAIN_, HYPK_)                                                                                  \
+    hipLaunchKernelGGL((k_finalize<R, 0, 1, false, PLAIN_, HYPK_>), grid, dim3(MERGE_THREADS), lds, s, F.partials, F.heads, \
+                       st, (const void *)F.u, F.T, F)
+        if (F.hyp) { if (plain) MPPI_FIN_SINGLE(true, true); else MPPI_FIN_SINGLE(false, true); }
+        else { if (plain) MPPI_FIN_SINGLE(true, false); else MPPI_FIN_SINGLE(false, false); }
+#undef MPPI_FIN_SINGLE
+    }
 #undef MPPI_FIN
 }
 
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) {
     hipLaunchKernelGGL(k_exchange_probe, dim3(1), dim3(64), 0, s, F, ok_out);
+}
+
+template <typename R>
+void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_costs<R>, dim3((K + 255) / 256), dim3(256), 0, s, hyp_S, hyp_q, S, K);
 }
 
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {
@@ -1777,6 +2037,7 @@ extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
     template void launch_merge<R>(const void *, const void *, int, int, int, double, void *, void *, bool, hipStream_t);        \
     template void launch_finalize<R>(const FinalizeParams &, bool, hipStream_t);                          \
     template void launch_weights<R>(const KParams<R> &, double, double, double *, hipStream_t);           \
+    template void launch_gather_costs<R>(const R *, const unsigned char *, R *, int, hipStream_t);          \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)

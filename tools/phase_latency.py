@@ -13,5 +13,7 @@ res = []
 for rep in range(6):
     t0 = time.perf_counter(); eng.run_closed_loop(3000); torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 3000 * 1e6)
 eng.set_u_prev(np.zeros((50, 2))); eng.set_waypoint_idx(0); eng.set_state(np.zeros(3)); torch.cuda.synchronize()
-t0 = time.perf_counter(); eng.run_closed_loop(25); torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / 25 * 1e6
+t0 = time.perf_counter(); eng.run_closed_loop(23); torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / 23 * 1e6
+eng.run_closed_loop(200); eng.enable_timing(True); eng.run_closed_loop(2000); torch.cuda.synchronize(); km = eng.last_kernel_ms(); eng.enable_timing(False)
+print("  hold-phase event pairs: rollout %.2f finalize %.2f us" % (1e3 * km["rollout"], 1e3 * km["finalize"]))
 print(os.environ.get("MPPI_LIB", "new")[-12:], "hold min %.2f med %.2f" % (min(res), sorted(res)[3]), "traverse %.1f" % tr)
