@@ -1395,7 +1395,15 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     unsigned long long peer_ptr = 0;
     if (XCHG) peer_ptr = load_peer_ptrs(F);
     MergeRegs<A, NT, NWIN> mr;
-    if (!ABI_RECS) {
+    // (HYPK: which records there are to merge -- the compact ones or the realised entries of the one-launch resolution --
+    // is known once the state is here; wave 0 fetches the workgroups' maps meanwhile, four per lane)
+    uint4 hmap[4] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+    if (HYPK) {
+        if (wid == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hmap[j] = reinterpret_cast<const uint4 *>(F.hyp_map)[4 * lane + j];
+        }
+    } else if (!ABI_RECS) {
         merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
         merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
@@ -1450,45 +1458,49 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     const unsigned char *sel = nullptr;  // != null: the records to merge are the realised entries of the HYP_R per workgroup
     if (HYPK) {  // (launched with the HYPK rollout kernel: the same condition there)
         static_assert(!HYPK || (MODE == 0 && NWIN == 1 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
-        if (round == 0 && min(F.window, F.n_ref - c_state) > 1) {
-            unsigned char *sh_map = reinterpret_cast<unsigned char *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));
-            unsigned char *sh_G = sh_map + HYP_MAX_BLOCKS * HYP_R;  // [16][HYP_R]: groups of 16 workgroups
-            unsigned char *sh_ent = sh_G + 16 * HYP_R;              // [16] offset each group is entered at
-            unsigned char *sh_q = sh_ent + 16;                      // [256] offset each workgroup is entered at
+        const bool hyp_round = round == 0 && min(F.window, F.n_ref - c_state) > 1;
+        if (!hyp_round) {  // a speculation round, or nothing can move: the compact records as in the lean kernel
+            merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
+            merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
+        } else {
+            unsigned char *sh_q = reinterpret_cast<unsigned char *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));  // [256]
             int *sh_i = reinterpret_cast<int *>(sh_q + HYP_MAX_BLOCKS);  // {first workgroup that leaves the table, final offset}
             const int nb = F.hyp_blocks;
-            *reinterpret_cast<uint4 *>(sh_map + HYP_R * tid) = *reinterpret_cast<const uint4 *>(F.hyp_map + HYP_R * tid);
-            if (tid == 0) sh_i[0] = INT_MAX;
-            __syncthreads();
-            {   // every group of 16 workgroups as one map: thread = (group, entry offset), 16 chained byte reads
-                const int g = tid >> 4, Q = tid & 15;
-                int p = Q;
-                for (int j = 0; j < 16; ++j) {
-                    const int b = 16 * g + j;
-                    if (b < nb) p = p < HYP_R ? (int)sh_map[HYP_R * b + p] : HYP_OVF;
-                }
-                sh_G[HYP_R * g + Q] = (unsigned char)p;
-            }
-            __syncthreads();
-            if (tid < 16) {  // the offset group `tid` is entered at: the iteration enters at 0 (the x0 call's index)
-                int p = 0;
-                for (int j = 0; j < tid; ++j) p = p < HYP_R ? (int)sh_G[HYP_R * j + p] : HYP_OVF;
-                sh_ent[tid] = (unsigned char)p;
-            }
-            __syncthreads();
-            if (tid < 16) {  // and every workgroup of the group
-                int p = sh_ent[tid], first = INT_MAX;
-                for (int j = 0; j < 16; ++j) {
-                    const int b = 16 * tid + j;
-                    sh_q[b] = (unsigned char)p;
-                    if (b < nb) {
-                        const int nxt = p < HYP_R ? (int)sh_map[HYP_R * b + p] : HYP_OVF;
-                        if (p < HYP_R && nxt == HYP_OVF && first == INT_MAX) first = b;
-                        p = nxt;
+            if (wid == 0) {
+                // Compose the workgroups' maps from offset 0 (the x0 call's index).  Nearly all of them leave the offset
+                // they are entered at unchanged, so: every lane looks its four maps up at the current offset p, the first
+                // workgroup whose value differs takes p there, and again from the workgroup behind it -- one trip per
+                // workgroup that moves the index (a handful per iteration), no memory access inside.
+                int qv[4] = {0, 0, 0, 0};
+                int p = 0, start = 0, ovf = INT_MAX;
+                for (;;) {
+                    int nxt[4];
+                    bool mv[4];
+                    const int pw = p >> 2, ps = 8 * (p & 3);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w4 = pw == 0 ? hmap[j].x : pw == 1 ? hmap[j].y : pw == 2 ? hmap[j].z : hmap[j].w;
+                        nxt[j] = (int)((w4 >> ps) & 255u);
+                        const int b = 4 * lane + j;
+                        if (b >= start) qv[j] = p;
+                        mv[j] = b >= start && b < nb && nxt[j] != p;
                     }
+                    const unsigned long long m = __ballot(mv[0] | mv[1] | mv[2] | mv[3]);
+                    if (m == 0ull) break;
+                    const int fl = __builtin_ctzll(m);
+                    const int jf = mv[0] ? 0 : mv[1] ? 1 : mv[2] ? 2 : 3;
+                    const int nf = mv[0] ? nxt[0] : mv[1] ? nxt[1] : mv[2] ? nxt[2] : nxt[3];
+                    const int bf = 4 * fl + __builtin_amdgcn_readlane(jf, fl), pn = __builtin_amdgcn_readlane(nf, fl);
+                    if (pn >= HYP_R) {  // (HYP_OVF) workgroup bf's chain leaves the table from its entry p
+                        ovf = bf;
+                        break;
+                    }
+                    p = pn;
+                    start = bf + 1;
                 }
-                if (first != INT_MAX) atomicMin(&sh_i[0], first);
-                if (tid == 15) sh_i[1] = p;
+                *reinterpret_cast<unsigned *>(sh_q + 4 * lane) =
+                    (unsigned)qv[0] | ((unsigned)qv[1] << 8) | ((unsigned)qv[2] << 16) | ((unsigned)qv[3] << 24);
+                if (lane == 0) { sh_i[0] = ovf; sh_i[1] = p; }
             }
             __syncthreads();
             const int b_ovf = sh_i[0];
@@ -1966,7 +1978,7 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_rec
     // (+ the staging area of the peer-to-peer exchange; merge_lds_elems is a multiple of 4 elements: 16-byte aligned)
     const size_t lds = merge_lds(F.T, F.filter_window, sizeof(R)) +
                        (F.x_nranks > 1 ? sizeof(double) * XCHG_LDS_RANKS * xchg_rec_len(F.T) : 0) +
-                       (F.hyp ? (size_t)HYP_MAX_BLOCKS * HYP_R + 16 * HYP_R + 16 + HYP_MAX_BLOCKS + 16 : 0);
+                       (F.hyp ? (size_t)HYP_MAX_BLOCKS + 16 : 0);
     const DevState *st = F.st;
     const bool two = F.n_part > MERGE_MAX_RECORDS;  // (at most MERGE_MAX_WINDOWS * 256: the caller merges above that)
     const bool multi = !abi_recs && F.x_nranks <= 1 && F.n_agents > 1;  // one workgroup per agent

@@ -17,3 +17,6 @@ t0 = time.perf_counter(); eng.run_closed_loop(23); torch.cuda.synchronize(); tr 
 eng.run_closed_loop(200); eng.enable_timing(True); eng.run_closed_loop(2000); torch.cuda.synchronize(); km = eng.last_kernel_ms(); eng.enable_timing(False)
 print("  hold-phase event pairs: rollout %.2f finalize %.2f us" % (1e3 * km["rollout"], 1e3 * km["finalize"]))
 print(os.environ.get("MPPI_LIB", "new")[-12:], "hold min %.2f med %.2f" % (min(res), sorted(res)[3]), "traverse %.1f" % tr)
+eng.set_u_prev(np.zeros((50, 2))); eng.set_waypoint_idx(0); eng.set_state(np.zeros(3)); torch.cuda.synchronize()
+eng.enable_timing(True); eng.run_closed_loop(22); torch.cuda.synchronize(); km = eng.last_kernel_ms(); eng.enable_timing(False)
+print("  traversal event pairs: rollout %.2f finalize %.2f us (pair overhead %.2f)" % (1e3 * km["rollout"], 1e3 * km["finalize"], 1e3 * km["event_pair_overhead"]), eng.counters())
