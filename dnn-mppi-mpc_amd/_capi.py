@@ -93,6 +93,14 @@ PROTOTYPES = {
     "mppi_enable_timing": (C.c_int, [_H, C.c_int32]),
     "mppi_set_rollout_repeats": (C.c_int, [_H, C.c_int32]),
     "mppi_get_counters": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "mppi_step_device_x0": (C.c_int, [_H, C.c_void_p, C.c_void_p, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
+    "mppi_eval_state_transition": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
+    "mppi_eval_clamp": (C.c_int, [_H, _D, C.c_int32, _D]),
+    "mppi_eval_is_collided": (C.c_int, [_H, _D, C.c_int32, _D]),
+    "mppi_eval_nearest_waypoint": (C.c_int, [_H, _D, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
+    "mppi_eval_cost": (C.c_int, [_H, C.c_int32, _D, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _D, C.POINTER(C.c_int32)]),
+    "mppi_eval_moving_average": (C.c_int, [_H, _D, _D]),
+    "mppi_eval_weights": (C.c_int, [_H, _D, C.c_int32, _D]),
 }
 
 _lib = None
@@ -115,10 +123,13 @@ def load_library(path: str | None = None):
     except ImportError:
         pass
     lib = C.CDLL(p)
+    ab_build = bool(os.environ.get("MPPI_LIB")) and path is None  # an older diagnostic build may lack the newest entry points
     for name, (res, args) in PROTOTYPES.items():
+        if ab_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mppi_abi_version() != ABI_VERSION:
+    if lib.mppi_abi_version() != ABI_VERSION and not ab_build:
         raise MppiError(ERR_BAD_ARG, "ABI version mismatch between _capi.py and libmppi_hip.so")
     if path is None:
         _lib = lib

@@ -311,10 +311,76 @@ class _ControllerBase:
         smp = smp_t.cpu().numpy().astype(np.float64) if smp_t is not None else self._zero_smp
         return opt, smp
 
-    # -- batched stage equivalents used by callers/tests ----------------------------------------------------
+    # -- the stage methods of the reference classes, batched -------------------------------
+    # A single state / control (the reference's call shape) returns what the reference returns; an [n, .] array
+    # evaluates n calls in one launch.  Methods that move the waypoint index in the reference (`_compute_cost`,
+    # `_terminal_cost` of the diff-drive: `update_prev_idx=True`, mppi_differential_drive.py:228,:244) thread it through
+    # the n calls in order and leave it in `prev_way_point_idx`, as n successive reference calls would.
+    @staticmethod
+    def _as_rows(a, ncol):
+        a = _arr(a)
+        single = a.ndim == 1
+        a = a.reshape(1, -1) if single else a
+        if a.ndim != 2 or a.shape[1] != ncol:
+            raise ValueError(f"expected {ncol} values per row")
+        return a, single
+
+    def _transition(self, x_t, v_t):
+        x, single = self._as_rows(x_t, self.dim_x)
+        v, _ = self._as_rows(v_t, self.dim_u)
+        self._sync_state_to_device()
+        out = self._engine.eval_state_transition(x, v)
+        return out[0] if single else out
+
+    def _stage_or_terminal_cost(self, x_t, terminal, update):
+        x, single = self._as_rows(x_t, self.dim_x)
+        self._sync_state_to_device()
+        cost, _, p = self._engine.eval_cost(x, self._idx_host, terminal=terminal, update_prev_idx=update)
+        if update:
+            self._idx_host = int(p)
+        return float(cost[0]) if single else cost
+
+    def _is_collided(self, x_t):
+        """`_is_collided` (mppi_differential_drive_obs.py:301-313 / mppi_race_car_obstacle.py:255-274): 1.0 / 0.0."""
+        x, single = self._as_rows(x_t, self.dim_x)
+        hit = self._engine.eval_is_collided(x)
+        return float(hit[0]) if single else hit
+
+    def _nearest(self, x, y, update_prev_idx):
+        xa, ya = np.atleast_1d(_arr(x)).reshape(-1), np.atleast_1d(_arr(y)).reshape(-1)
+        single = np.ndim(x) == 0
+        rows = np.zeros((xa.size, self.dim_x))
+        rows[:, 0], rows[:, 1] = xa, ya
+        self._sync_state_to_device()
+        idx, p = self._engine.eval_nearest_waypoint(rows, self._idx_host, update_prev_idx)
+        if update_prev_idx:
+            self._idx_host = int(p)
+        ref = self._ref_path[idx]
+        cols = [idx] + [ref[:, j] for j in range(ref.shape[1])]
+        return tuple(c[0] for c in cols) if single else tuple(cols)
+
+    def _moving_average_filter(self, xx, window_size=10):
+        """`_moving_average_filter` (mppi_differential_drive.py:257-271 / mppi_race_car.py:211-222 / the torch files'
+        conv1d form) of a [T, 2] signal, evaluated by the finalize kernel's filter code."""
+        if int(window_size) != 10:
+            raise ValueError("the engine is built for the reference's window_size = 10")
+        return self._engine.eval_moving_average(_arr(xx)).astype(self._ref_dtype)
+
     def _compute_weight(self, S=None):
-        """`_compute_weight` (:167-180) of the last iteration's costs, evaluated on the GPU."""
-        return self._engine.weights()
+        """`_compute_weight` (:167-180 / mppi_race_car.py:199-209): of ``S`` when given (the reference's signature), else of
+        the last iteration's costs; evaluated on the GPU."""
+        if S is None:
+            return self._engine.weights()
+        return self._engine.eval_weights(_arr(S))
+
+    def _g(self, v):
+        """`_g` (:285-289 / mppi_race_car.py:176-181): clamps in place like the reference and returns ``v``."""
+        a, _ = self._as_rows(v, self.dim_u)
+        out = self._engine.eval_clamp(a).reshape(np.shape(v))
+        if isinstance(v, np.ndarray):
+            v[...] = out
+            return v
+        return out
 
     def sample_costs(self):
         """S[K] of the last iteration (`S`, :103)."""
@@ -400,12 +466,23 @@ class MPPIAlgorithms(_ControllerBase):
         opt, smp = self._viz(want, want)
         return self._u_host[0], self._u_host, opt, smp
 
-    def _g(self, v):
-        """`_g` :285-289, batched over leading dimensions (host utility)."""
-        v = np.asarray(v)
-        v[..., 0] = np.clip(v[..., 0], -self.max_speed, self.max_speed)
-        v[..., 1] = np.clip(v[..., 1], -self.max_omega, self.max_omega)
-        return v
+    def _state_transition(self, x_t, v_t):
+        """`_state_transition` (:182-198): Euler step of the unicycle (of the residual model when one is loaded: not built)."""
+        if self._learned:
+            raise NotImplementedError("the batched transition of the learned model is not exposed")
+        return self._transition(x_t, v_t)
+
+    def _compute_cost(self, x_t):
+        """`_compute_cost` (:222-236; `_obs.py:228-244` adds the collision term); moves `prev_way_point_idx` (:228)."""
+        return self._stage_or_terminal_cost(x_t, terminal=False, update=True)
+
+    def _terminal_cost(self, x_T):
+        """`_terminal_cost` (:239-249); moves `prev_way_point_idx` (:244)."""
+        return self._stage_or_terminal_cost(x_T, terminal=True, update=True)
+
+    def _get_nearest_waypoint(self, x, y, update_prev_idx=False):
+        """`_get_nearest_waypoint` (:201-220) -> (nearest_idx, ref_x, ref_y, ref_yaw)."""
+        return self._nearest(x, y, update_prev_idx)
 
 
 class MPPIRacecarController(_ControllerBase):
@@ -481,8 +558,18 @@ class MPPIRacecarController(_ControllerBase):
         opt, smp = self._viz(self.visualize_optimal_traj, self.visualze_sampled_trajs)
         return self._u_host[0], self._u_host, opt.astype(np.float32), smp.astype(np.float32)
 
-    def _g(self, v):
-        v = np.asarray(v)
-        v[..., 0] = np.clip(v[..., 0], -self.max_steer_abs, self.max_steer_abs)
-        v[..., 1] = np.clip(v[..., 1], -self.max_accel_abs, self.max_accel_abs)
-        return v
+    def _F(self, x_t, v_t):
+        """`_F` (mppi_race_car.py:183-197): Euler step of the kinematic bicycle, controls [steer, accel]."""
+        return self._transition(x_t, v_t).astype(np.float32)
+
+    def _c(self, x_t):
+        """`_c` (mppi_race_car.py:137-146; `_obstacle.py:147-158` adds the collision term); the index stays (:143)."""
+        return self._stage_or_terminal_cost(x_t, terminal=False, update=False)
+
+    def _phi(self, x_T):
+        """`_phi` (mppi_race_car.py:148-155)."""
+        return self._stage_or_terminal_cost(x_T, terminal=True, update=False)
+
+    def get_nearest_waypoint(self, x, y, update_prev_idx=False):
+        """`get_nearest_waypoint` (mppi_race_car.py:157-174) -> (nearest_idx, ref_x, ref_y, ref_yaw, ref_v)."""
+        return self._nearest(x, y, update_prev_idx)

@@ -728,13 +728,18 @@ static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
     return MPPI_OK;
 }
 
+// x0: host (the observed state travels as kernel arguments) or, when null, x0_dev: device memory (a small kernel moves
+// it into the controller state and makes the x0 call)
 template <typename R>
-static int step_impl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
+static int step_impl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
-    const bool by_args = h->idx_valid && h->by_args_ok;
-    if (by_args) {
+    const bool by_args = x0 && h->idx_valid && h->by_args_ok;
+    if (!x0) {
+        if (!h->idx_valid) FAIL(h, MPPI_ERR_STATE, "mppi_step_device_x0 after an asynchronous split step: call mppi_sync_result first");
+        launch_set_state_dev<R>(P, x0_dev, h->nx, s);
+    } else if (by_args) {
         P.use_args = F.use_args = 1;
         P.c_arg = F.c_arg = host_x0_call(h, x0);
         P.hyp = F.hyp = h->hyp && P.c_arg < h->n_ref - 1;  // (a window of one candidate: nothing can move)
@@ -779,8 +784,19 @@ extern "C" int mppi_step(mppi_handle *h, const double *x0, const float *eps, dou
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     double x[4] = {0, 0, 0, 0};
     for (int i = 0; i < h->nx; ++i) x[i] = x0[i];
-    return h->f64 ? step_impl<double>(h, x, eps, u_out, u0_out, stats, (hipStream_t)stream)
-                  : step_impl<float>(h, x, eps, u_out, u0_out, stats, (hipStream_t)stream);
+    return h->f64 ? step_impl<double>(h, x, nullptr, eps, u_out, u0_out, stats, (hipStream_t)stream)
+                  : step_impl<float>(h, x, nullptr, eps, u_out, u0_out, stats, (hipStream_t)stream);
+}
+
+extern "C" int mppi_step_device_x0(mppi_handle *h, const double *x0_device, const float *eps, double *u_out, double *u0_out,
+                                   mppi_stats *stats, void *stream) {
+    int rc = check_ready(h, "mppi_step_device_x0");
+    if (rc) return rc;
+    SINGLE_AGENT_ONLY(h, "mppi_step_device_x0");
+    if (!x0_device) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_step_device_x0: x0 is null");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    return h->f64 ? step_impl<double>(h, nullptr, x0_device, eps, u_out, u0_out, stats, (hipStream_t)stream)
+                  : step_impl<float>(h, nullptr, x0_device, eps, u_out, u0_out, stats, (hipStream_t)stream);
 }
 
 extern "C" int mppi_partial_len(const mppi_handle *h, int32_t *n) {
@@ -1145,6 +1161,122 @@ extern "C" int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     return h->f64 ? closed_loop_impl<double>(h, n_iters, u0_trace, stats, (hipStream_t)stream)
                   : closed_loop_impl<float>(h, n_iters, u0_trace, stats, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched stage methods (include/mppi_hip.h, mppi_eval_*): host arrays in, host arrays out; the arithmetic is the
+// device code of the rollout kernels in the handle's precision.
+// ------------------------------------------------------------------------------------------
+struct DevBuf {  // scratch device buffer released at scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+template <typename R>
+static int eval_impl(mppi_handle *h, int what, const double *x, const double *v, int n, int32_t *prev_idx, int update,
+                     double *out, int32_t *idx_out) {
+    const KParams<R> P = make_params<R>(h, nullptr);
+    const int nx = h->nx;
+    const bool need_x = what != EVAL_CLAMP, need_v = what == EVAL_TRANSITION || what == EVAL_CLAMP;
+    const bool need_idx = what == EVAL_COST_STAGE || what == EVAL_COST_TERMINAL || what < 0;  // what < 0: index only
+    const int n_out = what == EVAL_TRANSITION ? nx : what == EVAL_CLAMP ? 2 : 1;
+    DevBuf dx, dv, di, dp, dout;
+    if (need_x) {
+        HIPCHECK(h, dx.alloc(sizeof(R) * (size_t)n * nx));
+        if (int rc = upload_real(h, dx.p, x, (size_t)n * nx)) return rc;
+    }
+    if (need_v) {
+        HIPCHECK(h, dv.alloc(sizeof(R) * (size_t)n * 2));
+        if (int rc = upload_real(h, dv.p, v, (size_t)n * 2)) return rc;
+    }
+    if (need_idx) {
+        if (!prev_idx) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_eval: prev_idx is null");
+        if (*prev_idx < 0 || *prev_idx >= h->n_ref) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_eval: waypoint index %d out of range", *prev_idx);
+        HIPCHECK(h, di.alloc(sizeof(int) * (size_t)n));
+        HIPCHECK(h, dp.alloc(sizeof(int)));
+        launch_eval_index<R>(P, (const R *)dx.p, nx, n, *prev_idx, update ? 1 : 0, (int *)di.p, (int *)dp.p, nullptr);
+    }
+    if (what >= 0) {
+        HIPCHECK(h, dout.alloc(sizeof(R) * (size_t)n * n_out));
+        launch_eval<R>(P, what, (const R *)dx.p, (const R *)dv.p, (const int *)di.p, n, (R *)dout.p, nullptr);
+    }
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipDeviceSynchronize());
+    if (what >= 0)
+        if (int rc = download_real(h, out, dout.p, (size_t)n * n_out)) return rc;
+    if (need_idx) {
+        if (idx_out) HIPCHECK(h, hipMemcpy(idx_out, di.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+        int pn = *prev_idx;
+        HIPCHECK(h, hipMemcpy(&pn, dp.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (update) *prev_idx = pn;
+    }
+    return MPPI_OK;
+}
+
+static int eval_entry(mppi_handle *h, const char *who, int what, const double *x, const double *v, int n, int32_t *prev_idx,
+                      int update, double *out, int32_t *idx_out) {
+    int rc = check_ready(h, who);
+    if (rc) return rc;
+    if (n < 1 || (what >= 0 && !out)) FAIL(h, MPPI_ERR_BAD_ARG, "%s: bad argument", who);
+    if ((what != EVAL_CLAMP && !x) || ((what == EVAL_TRANSITION || what == EVAL_CLAMP) && !v))
+        FAIL(h, MPPI_ERR_BAD_ARG, "%s: null input", who);
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    return h->f64 ? eval_impl<double>(h, what, x, v, n, prev_idx, update, out, idx_out)
+                  : eval_impl<float>(h, what, x, v, n, prev_idx, update, out, idx_out);
+}
+
+extern "C" int mppi_eval_state_transition(mppi_handle *h, const double *x, const double *v, int32_t n, double *x_next) {
+    return eval_entry(h, "mppi_eval_state_transition", EVAL_TRANSITION, x, v, n, nullptr, 0, x_next, nullptr);
+}
+extern "C" int mppi_eval_clamp(mppi_handle *h, const double *v, int32_t n, double *out) {
+    return eval_entry(h, "mppi_eval_clamp", EVAL_CLAMP, nullptr, v, n, nullptr, 0, out, nullptr);
+}
+extern "C" int mppi_eval_is_collided(mppi_handle *h, const double *x, int32_t n, double *out) {
+    return eval_entry(h, "mppi_eval_is_collided", EVAL_COLLIDED, x, nullptr, n, nullptr, 0, out, nullptr);
+}
+extern "C" int mppi_eval_nearest_waypoint(mppi_handle *h, const double *x, int32_t n, int32_t *prev_idx, int32_t update_prev_idx,
+                                          int32_t *idx_out) {
+    if (h && !idx_out) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_eval_nearest_waypoint: idx_out is null");
+    return eval_entry(h, "mppi_eval_nearest_waypoint", -1, x, nullptr, n, prev_idx, update_prev_idx, nullptr, idx_out);
+}
+extern "C" int mppi_eval_cost(mppi_handle *h, int32_t terminal, const double *x, int32_t n, int32_t *prev_idx,
+                              int32_t update_prev_idx, double *cost, int32_t *idx_out) {
+    return eval_entry(h, "mppi_eval_cost", terminal ? EVAL_COST_TERMINAL : EVAL_COST_STAGE, x, nullptr, n, prev_idx,
+                      update_prev_idx, cost, idx_out);
+}
+
+extern "C" int mppi_eval_moving_average(mppi_handle *h, const double *xx, double *out) {
+    if (!h || !xx || !out) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    const int T = h->cfg.T;
+    DevBuf in, o;
+    HIPCHECK(h, in.alloc(rsz(h) * 2 * T));
+    HIPCHECK(h, o.alloc(rsz(h) * 2 * T));
+    if (int rc = upload_real(h, in.p, xx, (size_t)2 * T)) return rc;
+    if (h->f64) launch_eval_filter<double>((const double *)in.p, (double *)o.p, T, h->cfg.filter_window, h->cfg.filter_mode, nullptr);
+    else launch_eval_filter<float>((const float *)in.p, (float *)o.p, T, h->cfg.filter_window, h->cfg.filter_mode, nullptr);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipDeviceSynchronize());
+    return download_real(h, out, o.p, (size_t)2 * T);
+}
+
+extern "C" int mppi_eval_weights(mppi_handle *h, const double *S, int32_t n, double *w) {
+    if (!h || !S || !w || n < 1) return MPPI_ERR_BAD_ARG;
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    DevBuf in, o;
+    HIPCHECK(h, in.alloc(sizeof(double) * (size_t)n));
+    HIPCHECK(h, o.alloc(sizeof(double) * (size_t)n));
+    HIPCHECK(h, hipMemcpy(in.p, S, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    const mppi_config &c = h->cfg;
+    const double beta = c.beta_mode == MPPI_BETA_INV_EXPLORATION ? 1.0 / c.param_exploration
+                        : c.beta_mode == MPPI_BETA_INV_LAMBDA    ? 1.0 / c.param_lambda
+                                                                 : c.param_lambda;
+    launch_eval_weights((const double *)in.p, n, beta, (double *)o.p, nullptr);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipDeviceSynchronize());
+    HIPCHECK(h, hipMemcpy(w, o.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return MPPI_OK;
 }
 
 extern "C" int mppi_get_counters(mppi_handle *h, int64_t *out3) {

@@ -193,6 +193,16 @@ void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s);
 // S[k] of an iteration that ended in the one-launch resolution (StepResult::costs_hyp)
 template <typename R>
 void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K, hipStream_t s);
+// batched stage methods (mppi_eval_*): `what` of launch_eval
+enum { EVAL_TRANSITION = 0, EVAL_COST_STAGE = 1, EVAL_COST_TERMINAL = 2, EVAL_COLLIDED = 3, EVAL_CLAMP = 4 };
+template <typename R>
+void launch_eval_index(const KParams<R> &P, const R *xy, int stride, int n, int p0, int sequential, int *idx_out, int *p_out,
+                       hipStream_t s);
+template <typename R>
+void launch_eval(const KParams<R> &P, int what, const R *x, const R *v, const int *idx, int n, R *out, hipStream_t s);
+template <typename R> void launch_eval_filter(const R *xx, R *out, int T, int W, int mode, hipStream_t s);
+void launch_eval_weights(const double *S, int n, double beta, double *w, hipStream_t s);
+template <typename R> void launch_set_state_dev(const KParams<R> &P, const double *x_dev, int nx, hipStream_t s);
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w_out, hipStream_t s);
 void launch_sample(unsigned seed_lo, unsigned seed_hi, unsigned iter, int K, int T, int k_offset, const float *chol,
                    float *eps_out, hipStream_t s, unsigned stream_word = 0);

@@ -1078,6 +1078,51 @@ __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // 1 ulp
 __device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
 
+// ---- the moving average of the weighted noise (`_moving_average_filter`), shared by k_finalize and k_eval_filter ----
+// Sample t of channel d sits at sh_w[2 (t + H) + d], H = W / 2: H leading and W - H trailing slots hold zeros
+// (np.convolve 'same', mppi_differential_drive.py:257-263) or copies of the first / last H samples
+// (mppi_race_car.py:211-222: the padded signal is xx[:H] + xx + xx[-H:])
+template <typename A> __device__ __forceinline__ void filter_store(A *sh_w, int i, A v, int T, int H, bool pad_copy) {
+    const int t = i >> 1, d = i & 1;
+    const A pv = pad_copy ? v : A(0);
+    sh_w[2 * (t + H) + d] = v;
+    if (t < H) sh_w[2 * t + d] = pv;
+    if (t >= T - H) sh_w[2 * (t + 2 * H) + d] = pv;
+    if (t == T - 1) sh_w[2 * (T + 2 * H) + d] = pv;  // odd W only
+}
+// filtered sample t of channel d (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order
+template <typename A> __device__ __forceinline__ A filter_at(const A *sh_w, int t, int d, int T, int W, int f_filter) {
+    const int H = W / 2;
+    const A inv_w = fast_div(A(1), (A)W);
+    if (f_filter == FILTER_NONE) return sh_w[2 * (t + H) + d];
+    if (f_filter == FILTER_TORCH) {
+        // conv1d(padding = H) over the padded signal, first T outputs (mppi_race_car_torch.py:211-222):
+        // output t = padded rows t-H .. t-H+W-1, rows before the start are the convolution's zero padding
+        A sacc = 0;
+        for (int q = 0; q < W; ++q) {
+            const int m = t - H + q;
+            if (m >= 0) sacc += sh_w[2 * m + d] * inv_w;
+        }
+        return sacc;
+    }
+    const A *tap = sh_w + 2 * t + d;
+    A sacc = 0;
+    if (W == 10) {  // every reference variant; static LDS offsets, reads issue back to back
+#pragma unroll
+        for (int q = 0; q < 10; ++q) sacc += tap[2 * (9 - q)] * inv_w;
+    } else {
+        for (int q = 0; q < W; ++q) sacc += tap[2 * (W - 1 - q)] * inv_w;
+    }
+    if (f_filter == FILTER_DIFF) {  // the edge factors of mppi_differential_drive.py:265-269
+        const int n_conv = (W + 1) / 2;
+        if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
+        else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
+        if (t == T - 1)
+            for (int q = 1; q < n_conv; ++q) sacc *= fast_div((A)W, (A)(q + n_conv - (W % 2)));
+    }
+    return sacc;
+}
+
 template <typename A> struct BlockRed {  // block-wide reductions through one LDS exchange each (256 threads)
     static __device__ __forceinline__ A min1(A v, A *sh, int tid) {
         v = wv::reduce<wv::OpMin>(v);
@@ -1565,18 +1610,9 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     if (f_plant) mf::sincos_((A)x0v[2], sn_yaw, cs_yaw);
     STAMP(17);
 
-    // w_eps lands in the padded layout the filter reads: H leading and W - H trailing slots hold zeros
-    // (np.convolve 'same', mppi_differential_drive.py:257-263) or copies of the first / last H samples
-    // (mppi_race_car.py:211-222: the padded signal is xx[:H] + xx + xx[-H:])
+    // w_eps lands in the padded layout the filter reads (filter_store)
     const bool pad_copy = f_filter == FILTER_RACE || f_filter == FILTER_TORCH;
-    auto store_w = [&](int i, A v) {
-        const int t = i >> 1, d = i & 1;
-        const A pv = pad_copy ? v : A(0);
-        sh_w[2 * (t + H) + d] = v;
-        if (t < H) sh_w[2 * t + d] = pv;
-        if (t >= T - H) sh_w[2 * (t + 2 * H) + d] = pv;
-        if (t == T - 1) sh_w[2 * (T + 2 * H) + d] = pv;  // odd W only
-    };
+    auto store_w = [&](int i, A v) { filter_store<A>(sh_w, i, v, T, H, pad_copy); };
     A rho, eta, eta2;
     if (ABI_RECS) {
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
@@ -1627,40 +1663,10 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         return leave();
     }
 
-    // --- moving average of w_eps (window W): taps padded[t + W - 1 - q], q = 0 .. W-1, in that order ------
-    const A inv_w = fast_div(A(1), (A)W);
+    // --- moving average of w_eps (window W) ------------------------------------------------------------------
     for (int i = tid; i < 2 * T; i += NT) {
         const int t = i >> 1, d = i & 1;
-        A f;
-        if (f_filter == FILTER_NONE) {
-            f = sh_w[2 * (t + H) + d];
-        } else if (f_filter == FILTER_TORCH) {
-            // conv1d(padding = H) over the padded signal, first T outputs (mppi_race_car_torch.py:211-222):
-            // output t = padded rows t-H .. t-H+W-1, rows before the start are the convolution's zero padding
-            A sacc = 0;
-            for (int q = 0; q < W; ++q) {
-                const int m = t - H + q;
-                if (m >= 0) sacc += sh_w[2 * m + d] * inv_w;
-            }
-            f = sacc;
-        } else {
-            const A *tap = sh_w + 2 * t + d;
-            A sacc = 0;
-            if (W == 10) {  // every reference variant; static LDS offsets, reads issue back to back
-#pragma unroll
-                for (int q = 0; q < 10; ++q) sacc += tap[2 * (9 - q)] * inv_w;
-            } else {
-                for (int q = 0; q < W; ++q) sacc += tap[2 * (W - 1 - q)] * inv_w;
-            }
-            if (f_filter == FILTER_DIFF) {  // the edge factors of mppi_differential_drive.py:265-269
-                const int n_conv = (W + 1) / 2;
-                if (t == 0) sacc *= fast_div((A)W, (A)n_conv);
-                else if (t < n_conv) sacc *= fast_div((A)W, (A)(t + n_conv));
-                if (t == T - 1)
-                    for (int q = 1; q < n_conv; ++q) sacc *= fast_div((A)W, (A)(q + n_conv - (W % 2)));
-            }
-            f = sacc;
-        }
+        const A f = filter_at<A>(sh_w, t, d, T, W, f_filter);
         const A uo = i == tid ? u_old : u_in[i];
         A un = uo + f;                                                        // u += w_epsilon, :141
         if (f_clamp_u) un = mf::clamp(un, d == 0 ? (A)F.umax0 : (A)F.umax1);  // :145-149
@@ -1846,6 +1852,120 @@ __global__ __launch_bounds__(256) void k_viz(const KParams<R> P, const R *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// The controller classes' stage methods, batched over n items (`_state_transition` / `_F`,
+// `_compute_cost` / `_c`, `_terminal_cost` / `_phi`, `_is_collided`, `_get_nearest_waypoint`, `_g`,
+// `_moving_average_filter`, `_compute_weight`) -- the same device functions the rollout kernels call, behind
+// mppi_eval_* of the C ABI.  Inspection / test entry points, not a hot path.
+// ------------------------------------------------------------------------------------------
+// waypoint index of n calls: every call searches [p0, p0 + window) (`update_prev_idx=False`, mppi_race_car.py:157-174), or
+// the index threads through the calls in order as n successive reference calls with `update_prev_idx=True` would
+// (mppi_differential_drive.py:201-220); xy = the first two columns of rows of `stride` elements
+template <typename R>
+__global__ __launch_bounds__(64) void k_eval_index(const R *__restrict__ ref, int n_ref, int window, const R *__restrict__ xy,
+                                                   int stride, int n, int p0, int sequential, int *__restrict__ idx_out,
+                                                   int *__restrict__ p_out) {
+    const int lane = threadIdx.x;
+    if (sequential) {  // one wave, candidates over the lanes, calls one after the other
+        int p = p0;
+        for (int i = 0; i < n; ++i) {
+            p = nearest_uniform(ref, p, window_len<R>(window, n_ref, p), xy[(size_t)i * stride], xy[(size_t)i * stride + 1], lane);
+            if (lane == 0) idx_out[i] = p;
+        }
+        if (lane == 0) *p_out = p;
+    } else {
+        const int i = blockIdx.x * 64 + lane;
+        if (i < n) idx_out[i] = nearest_in_window(ref, p0, window_len<R>(window, n_ref, p0), xy[(size_t)i * stride], xy[(size_t)i * stride + 1]);
+        if (i == 0) *p_out = p0;
+    }
+}
+
+template <typename R, int MODEL>
+__global__ __launch_bounds__(256) void k_eval(const KParams<R> P, int what, const R *__restrict__ x, const R *__restrict__ v,
+                                              const int *__restrict__ idx, int n, R *__restrict__ out) {
+    constexpr int NX = MODEL == MODEL_RACE ? 4 : 3;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const ObsLanes<R> obs = load_obstacles(P, lane);  // (lane m holds circle m: all lanes of the wave take part)
+    const bool act = i < n;
+    R s[4] = {R(0), R(0), R(0), R(0)}, v0 = 0, v1 = 0;
+    if (act && x)
+        for (int q = 0; q < NX; ++q) s[q] = x[(size_t)i * NX + q];
+    if (act && v) { v0 = v[2 * (size_t)i]; v1 = v[2 * (size_t)i + 1]; }
+    if (what == EVAL_TRANSITION) {
+        R sn, cs;
+        mf::sincos_(s[2], sn, cs);
+        if (MODEL == MODEL_DIFF) {  // mppi_differential_drive.py:182-198
+            s[0] += v0 * cs * P.dt;
+            s[1] += v0 * sn * P.dt;
+            s[2] += v1 * P.dt;
+        } else {  // mppi_race_car.py:183-197, controls = [steer, accel]
+            const R vel = s[3];
+            s[0] += vel * cs * P.dt;
+            s[1] += vel * sn * P.dt;
+            s[2] += vel / P.wheel_base * mf::tan_(v0) * P.dt;
+            s[3] += v1 * P.dt;
+        }
+        if (act)
+            for (int q = 0; q < NX; ++q) out[(size_t)i * NX + q] = s[q];
+    } else if (what == EVAL_CLAMP) {  // `_g`
+        if (act) {
+            out[2 * (size_t)i] = mf::clamp(v0, P.umax0);
+            out[2 * (size_t)i + 1] = mf::clamp(v1, P.umax1);
+        }
+    } else {
+        const bool hit = collided<MODEL == MODEL_RACE>(P, s[0], s[1], s[2], obs);
+        if (what == EVAL_COLLIDED) {
+            if (act) out[i] = hit ? R(1) : R(0);
+        } else {  // `_compute_cost` / `_c`, `_terminal_cost` / `_phi` at the given waypoint index
+            const bool term = what == EVAL_COST_TERMINAL;
+            R c = tracking_cost<R, MODEL>(P, term ? P.wt : P.ws, term ? P.wrap_term : P.wrap_stage, act ? idx[i] : 0, s[0], s[1],
+                                          s[2], s[3]);
+            if (hit) c += P.penalty;
+            if (act) out[i] = c;
+        }
+    }
+}
+
+// `_moving_average_filter` of a [T,2] signal in the handle's filter mode (one workgroup)
+template <typename A>
+__global__ __launch_bounds__(256) void k_eval_filter(const A *__restrict__ xx, A *__restrict__ out, int T, int W, int f_filter) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    A *sh_w = reinterpret_cast<A *>(smem);
+    const bool pad_copy = f_filter == FILTER_RACE || f_filter == FILTER_TORCH;
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) filter_store<A>(sh_w, i, xx[i], T, W / 2, pad_copy);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) out[i] = filter_at<A>(sh_w, i >> 1, i & 1, T, W, f_filter);
+}
+
+// `_compute_weight` of a given cost vector: w = exp(-beta (S - min S)) / sum (one workgroup, f64)
+__global__ __launch_bounds__(256) void k_eval_weights(const double *__restrict__ S, int n, double beta, double *__restrict__ w) {
+    __shared__ double sh[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double m = INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmin(m, S[i]);
+    m = wv::reduce<wv::OpMin>(m);
+    if (lane == 0) sh[wid] = m;
+    __syncthreads();
+    const double rho = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+    double a = 0.0;
+    for (int i = tid; i < n; i += 256) a += exp(-beta * (S[i] - rho));
+    a = wv::reduce<wv::OpAdd>(a);
+    if (lane == 0) sh[4 + wid] = a;
+    __syncthreads();
+    const double eta = sh[4] + sh[5] + sh[6] + sh[7];
+    for (int i = tid; i < n; i += 256) w[i] = exp(-beta * (S[i] - rho)) / eta;
+}
+
+// x0 of a synchronous step handed over in device memory (mppi_step_device_x0): into the state, then the x0 call
+template <typename R>
+__global__ __launch_bounds__(64) void k_set_state_dev(const R *ref, int n_ref, int window, int sequential, DevState *st,
+                                                      const double *__restrict__ x_dev, int nx) {
+    const int lane = threadIdx.x;
+    const double x0 = x_dev[0], x1 = x_dev[1];
+    if (lane < 4) st->x0[lane] = lane < nx ? x_dev[lane] : 0.0;
+    x0_call<R>(st, ref, n_ref, window, sequential, lane, x0, x1, st->p);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 int reduce_blocks(int K, int traj_per_block) { return (K + traj_per_block - 1) / traj_per_block; }
@@ -2012,6 +2132,28 @@ void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K
     hipLaunchKernelGGL(k_gather_costs<R>, dim3((K + 255) / 256), dim3(256), 0, s, hyp_S, hyp_q, S, K);
 }
 
+template <typename R>
+void launch_eval_index(const KParams<R> &P, const R *xy, int stride, int n, int p0, int sequential, int *idx_out, int *p_out,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_index<R>, dim3(sequential ? 1 : (n + 63) / 64), dim3(64), 0, s, P.ref, P.n_ref, P.window, xy,
+                       stride, n, p0, sequential, idx_out, p_out);
+}
+template <typename R>
+void launch_eval(const KParams<R> &P, int what, const R *x, const R *v, const int *idx, int n, R *out, hipStream_t s) {
+    const dim3 grid((n + 255) / 256), block(256);
+    if (P.model == MODEL_DIFF) hipLaunchKernelGGL((k_eval<R, MODEL_DIFF>), grid, block, 0, s, P, what, x, v, idx, n, out);
+    else hipLaunchKernelGGL((k_eval<R, MODEL_RACE>), grid, block, 0, s, P, what, x, v, idx, n, out);
+}
+template <typename R> void launch_eval_filter(const R *xx, R *out, int T, int W, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_filter<R>, dim3(1), dim3(256), sizeof(R) * 2 * (size_t)(T + W + 2), s, xx, out, T, W, mode);
+}
+void launch_eval_weights(const double *S, int n, double beta, double *w, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_weights, dim3(1), dim3(256), 0, s, S, n, beta, w);
+}
+template <typename R> void launch_set_state_dev(const KParams<R> &P, const double *x_dev, int nx, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_state_dev<R>, dim3(1), dim3(64), 0, s, P.ref, P.n_ref, P.window, P.sequential, P.st, x_dev, nx);
+}
+
 template <typename R> void launch_weights(const KParams<R> &P, double rho, double eta, double *w, hipStream_t s) {
     hipLaunchKernelGGL(k_weights<R>, dim3((P.K + 255) / 256), dim3(256), 0, s, P.S, P.K, (double)P.beta, rho, eta, w);
 }
@@ -2049,6 +2191,10 @@ extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
     template void launch_merge<R>(const void *, const void *, int, int, int, double, void *, void *, bool, hipStream_t);        \
     template void launch_finalize<R>(const FinalizeParams &, bool, hipStream_t);                          \
     template void launch_weights<R>(const KParams<R> &, double, double, double *, hipStream_t);           \
+    template void launch_eval_index<R>(const KParams<R> &, const R *, int, int, int, int, int *, int *, hipStream_t); \
+    template void launch_eval<R>(const KParams<R> &, int, const R *, const R *, const int *, int, R *, hipStream_t);   \
+    template void launch_eval_filter<R>(const R *, R *, int, int, int, hipStream_t);                                 \
+    template void launch_set_state_dev<R>(const KParams<R> &, const double *, int, hipStream_t);                     \
     template void launch_gather_costs<R>(const R *, const unsigned char *, R *, int, hipStream_t);          \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);
 INSTANTIATE(float)

@@ -152,8 +152,20 @@ class Engine:
 
     # -- the iteration ----------------------------------------------------------------------------
     def step(self, x0, eps=None, stream=None):
-        """One MPPI iteration.  ``eps``: CUDA float32 tensor [K,T,2] or None (on-device Philox).
-        Returns (u[T,2] shifted, u0[2], stats)."""
+        """One MPPI iteration.  ``eps``: CUDA float32 tensor [K,T,2] or None (on-device Philox).  ``x0``: host array, or a
+        float64 CUDA tensor [nx] handed over zero-copy (mppi_step_device_x0).  Returns (u[T,2] shifted, u0[2], stats)."""
+        if hasattr(x0, "is_cuda") and x0.is_cuda:
+            import torch
+            if x0.dtype != torch.float64 or tuple(x0.shape) != (self.nx,) or not x0.is_contiguous():
+                raise ValueError(f"a device x0 must be a contiguous float64 tensor with {self.nx} entries")
+            if eps is not None:
+                self._check_eps(eps)
+            _, up, u0p, stp = self._step_args
+            rc = self.lib.mppi_step_device_x0(self._h, C.c_void_p(x0.data_ptr()), _dev_ptr(eps), up, u0p, stp,
+                                              _stream_ptr(stream))
+            if rc:
+                self._ck(rc)
+            return self._u_buf.copy(), self._u0_buf.copy(), self.stats
         if np.shape(x0) != (self.nx,):
             raise ValueError(f"observed_x must have {self.nx} entries")
         self._x0_buf[:] = x0
@@ -251,6 +263,64 @@ class Engine:
         smp = torch.empty((self.K, self.T, self.nx), dtype=torch.float32, device=dev) if want_sampled else None
         self._ck(self.lib.mppi_rollout_viz(self._h, _dev_ptr(opt), _dev_ptr(smp), _stream_ptr(stream)))
         return opt, smp
+
+    # -- batched stage methods (include/mppi_hip.h, mppi_eval_*) -------------------------------------------
+    @staticmethod
+    def _rows(a, ncol):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != ncol:
+            raise ValueError(f"expected an [n, {ncol}] array")
+        return a
+
+    def eval_state_transition(self, x, v):
+        x, v = self._rows(x, self.nx), self._rows(v, 2)
+        if v.shape[0] != x.shape[0]:
+            raise ValueError("x and v must have the same number of rows")
+        out = np.empty_like(x)
+        self._ck(self.lib.mppi_eval_state_transition(self._h, _dp(x), _dp(v), x.shape[0], _dp(out)))
+        return out
+
+    def eval_clamp(self, v):
+        v = self._rows(v, 2)
+        out = np.empty_like(v)
+        self._ck(self.lib.mppi_eval_clamp(self._h, _dp(v), v.shape[0], _dp(out)))
+        return out
+
+    def eval_is_collided(self, x):
+        x = self._rows(x, self.nx)
+        out = np.empty(x.shape[0])
+        self._ck(self.lib.mppi_eval_is_collided(self._h, _dp(x), x.shape[0], _dp(out)))
+        return out
+
+    def eval_nearest_waypoint(self, x, prev_idx, update_prev_idx=False):
+        """Returns (idx[n], prev_idx after the calls)."""
+        x = self._rows(x, self.nx)
+        p, idx = C.c_int32(int(prev_idx)), np.empty(x.shape[0], dtype=np.int32)
+        self._ck(self.lib.mppi_eval_nearest_waypoint(self._h, _dp(x), x.shape[0], C.byref(p), int(bool(update_prev_idx)),
+                                                     idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return idx, p.value
+
+    def eval_cost(self, x, prev_idx, terminal=False, update_prev_idx=False):
+        """Returns (cost[n], idx[n], prev_idx after the calls)."""
+        x = self._rows(x, self.nx)
+        p, idx, cost = C.c_int32(int(prev_idx)), np.empty(x.shape[0], dtype=np.int32), np.empty(x.shape[0])
+        self._ck(self.lib.mppi_eval_cost(self._h, int(bool(terminal)), _dp(x), x.shape[0], C.byref(p),
+                                         int(bool(update_prev_idx)), _dp(cost), idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return cost, idx, p.value
+
+    def eval_moving_average(self, xx):
+        xx = np.ascontiguousarray(xx, dtype=np.float64)
+        if xx.shape != (self.T, 2):
+            raise ValueError(f"the filter input must be [{self.T}, 2]")
+        out = np.empty_like(xx)
+        self._ck(self.lib.mppi_eval_moving_average(self._h, _dp(xx), _dp(out)))
+        return out
+
+    def eval_weights(self, S):
+        S = np.ascontiguousarray(S, dtype=np.float64).reshape(-1)
+        w = np.empty_like(S)
+        self._ck(self.lib.mppi_eval_weights(self._h, _dp(S), S.size, _dp(w)))
+        return w
 
     def run_closed_loop(self, n_iters, trace=False, stream=None):
         tr = np.empty((n_iters, 2)) if trace else None

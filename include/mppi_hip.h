@@ -184,6 +184,11 @@ int mppi_get_waypoint_idx(mppi_handle *h, int32_t *idx);
 int mppi_step(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out,
               mppi_stats *stats, void *stream);
 
+/* The same with the observed state in DEVICE memory (nx doubles, e.g. a float64 CUDA tensor's data_ptr()): a state
+ * estimator that already lives on the GPU hands it over without a host round trip. */
+int mppi_step_device_x0(mppi_handle *h, const double *x0_device, const float *eps, double *u_out, double *u0_out,
+                        mppi_stats *stats, void *stream);
+
 /*
  * Split form for K sharded over ranks.  `begin` runs sample ->
  * rollout -> cost -> local softmin partial and writes this rank's record
@@ -249,6 +254,33 @@ int mppi_set_state(mppi_handle *h, const double *x);
 int mppi_get_state(mppi_handle *h, double *x);
 int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_trace /* host, nullable [n_iters,2] */,
                          mppi_stats *stats, void *stream);
+
+/*
+ * The stage methods of the controller classes as batched entry points, evaluated by the device
+ * code the rollout kernels use, in the handle's precision.  Host arrays of n items in and out.
+ *   mppi_eval_state_transition  `_state_transition` (mppi_differential_drive.py:182-198) / `_F` (mppi_race_car.py:183-197):
+ *                               x[n,nx], v[n,2] -> x_next[n,nx]   (no clamping: that is `_g`, mppi_eval_clamp)
+ *   mppi_eval_clamp             `_g` (:285-289 / mppi_race_car.py:176-181): v[n,2] -> clamped [n,2]
+ *   mppi_eval_is_collided       `_is_collided` (_obs.py:301-313 / mppi_race_car_obstacle.py:255-274): x[n,nx] -> {0,1}[n]
+ *   mppi_eval_nearest_waypoint  `_get_nearest_waypoint` (:201-220) / `get_nearest_waypoint` (mppi_race_car.py:157-174)
+ *                               for the positions x[n,nx] (columns 0,1), searched from *prev_idx.  update_prev_idx = 1:
+ *                               the index threads through the n calls in order, as n successive calls of the reference
+ *                               method would, and *prev_idx is left at the last one; 0: every call starts at *prev_idx
+ *   mppi_eval_cost              `_compute_cost` / `_c` (terminal = 0), `_terminal_cost` / `_phi` (terminal = 1): the
+ *                               weighted tracking error against the nearest waypoint (searched as above) + the
+ *                               collision penalty; idx_out (nullable) receives the waypoint index of every call
+ *   mppi_eval_moving_average    `_moving_average_filter` in the handle's filter mode: xx[T,2] -> [T,2]
+ *   mppi_eval_weights           `_compute_weight` of a given cost vector S[n] with the handle's softmin rate
+ */
+int mppi_eval_state_transition(mppi_handle *h, const double *x, const double *v, int32_t n, double *x_next);
+int mppi_eval_clamp(mppi_handle *h, const double *v, int32_t n, double *out);
+int mppi_eval_is_collided(mppi_handle *h, const double *x, int32_t n, double *out);
+int mppi_eval_nearest_waypoint(mppi_handle *h, const double *x, int32_t n, int32_t *prev_idx, int32_t update_prev_idx,
+                               int32_t *idx_out);
+int mppi_eval_cost(mppi_handle *h, int32_t terminal, const double *x, int32_t n, int32_t *prev_idx, int32_t update_prev_idx,
+                   double *cost, int32_t *idx_out);
+int mppi_eval_moving_average(mppi_handle *h, const double *xx, double *out);
+int mppi_eval_weights(mppi_handle *h, const double *S, int32_t n, double *w);
 
 /* Kernel durations by HIP events on the launch stream.  While enabled, every launch group of every
  * iteration is bracketed by an event pair, plus one empty pair that calibrates the cost of the
