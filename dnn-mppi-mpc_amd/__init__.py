@@ -11,6 +11,6 @@ from ._capi import MppiError, load_library
 from .build import build as build_library, source_id
 from .controllers import MPPIAlgorithms, MPPIRacecarController
 from .engine import Engine
-from . import paths
+from . import callback_mppi, paths
 
-__all__ = ["MPPIAlgorithms", "MPPIRacecarController", "Engine", "MppiError", "load_library", "build_library", "paths"]
+__all__ = ["MPPIAlgorithms", "MPPIRacecarController", "Engine", "MppiError", "load_library", "build_library", "paths", "callback_mppi"]

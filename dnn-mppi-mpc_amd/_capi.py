@@ -101,6 +101,16 @@ PROTOTYPES = {
     "mppi_eval_cost": (C.c_int, [_H, C.c_int32, _D, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _D, C.POINTER(C.c_int32)]),
     "mppi_eval_moving_average": (C.c_int, [_H, _D, _D]),
     "mppi_eval_weights": (C.c_int, [_H, _D, C.c_int32, _D]),
+    # pytorch_mppi-style MPPI with built-in models (callback_mppi.py binds the config struct)
+    "mppi_cb_last_error": (C.c_char_p, [_H]),
+    "mppi_cb_create": (C.c_int, [C.c_void_p, C.POINTER(_H)]),
+    "mppi_cb_destroy": (C.c_int, [_H]),
+    "mppi_cb_set_nominal": (C.c_int, [_H, _D]),
+    "mppi_cb_get_nominal": (C.c_int, [_H, _D]),
+    "mppi_cb_command": (C.c_int, [_H, _D, C.c_void_p, C.c_int32, _D, C.c_void_p]),
+    "mppi_cb_get_costs": (C.c_int, [_H, _D, _D]),
+    "mppi_cb_eval": (C.c_int, [_H, C.c_int32, _D, _D, C.c_int32, C.c_int32, _D]),
+    "mppi_cb_nominal_trajectory": (C.c_int, [_H, _D, _D]),
 }
 
 _lib = None

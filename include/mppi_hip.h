@@ -298,6 +298,56 @@ int mppi_set_rollout_repeats(mppi_handle *h, int32_t n);
  * mode may take several of each (speculation rounds); bench.py divides a measured time by these. */
 int mppi_get_counters(mppi_handle *h, int64_t *out3);
 
+/*
+ * `pytorch_mppi`-style MPPI with built-in dynamics / running-cost models: the callbacks the
+ * reference's test/test_mppi.py, test/test_mppi_diff.py, test/test_mppi_diff_dyna.py and
+ * train/bullet_mppi_differential_drive.py hand to `pytorch_mppi.MPPI`, as selectable device functions.  `mppi_cb_command`
+ * is `MPPI.command(state)`: shift the nominal sequence, sample, roll out, weigh, update, return the first action.
+ * The library itself is absent from the build container and un-pinned by the reference: the loop follows the
+ * published algorithm and is PARITY UNPINNED (csrc/mppi_cb.hip, oracle/mppi_cb_oracle.py).  fp32 like the callers.
+ */
+typedef enum {
+    MPPI_CB_DYN_UNICYCLE = 0,   /* test/test_mppi.py:12-26: [x, y, theta], [v, omega] */
+    MPPI_CB_DYN_SKID_STEER = 1  /* test/test_mppi_diff_dyna.py:13-40: [x, y, theta, v, omega], 4 wheel forces */
+} mppi_cb_dynamics;
+typedef enum {
+    MPPI_CB_OBS_INVERSE = 0,     /* 1 / (d + 1e-6) inside the safety distance (test/test_mppi.py:40-50) */
+    MPPI_CB_OBS_EXPONENTIAL = 1  /* exp(-(d - safety)), obstacles moving with the step index (test/test_mppi_diff.py:25-52) */
+} mppi_cb_obstacle_cost;
+typedef struct {
+    int32_t struct_size, device;
+    int32_t dynamics;            /* mppi_cb_dynamics: fixes nx (3 / 5) and nu (2 / 4) */
+    int32_t obstacle_kind;       /* mppi_cb_obstacle_cost */
+    int32_t K, T;                /* num_samples, horizon (T * nu <= 256) */
+    int32_t n_obs;               /* <= 16 */
+    int32_t sample_null_action;  /* the last sample applies the zero action (test_mppi_diff_dyna.py:338) */
+    double dt, lambda_;
+    double noise_sigma[16];      /* row-major, leading nu x nu block of a 4 x 4 */
+    double u_min[4], u_max[4], u_init[4];
+    double goal[5], q_diag[5], r_diag[4];
+    double obstacles[64];        /* [n_obs][4] = x, y, vx, vy (per step of the horizon) */
+    double safety_distance, obstacle_weight;
+    double skid_params[5];       /* m, I, r, L, damping (2.0, 0.05, 0.1, 0.4, 0.1 in the reference) */
+    uint64_t seed;
+} mppi_cb_config;
+typedef struct mppi_cb_handle mppi_cb_handle;
+const char *mppi_cb_last_error(const mppi_cb_handle *h);
+int mppi_cb_create(const mppi_cb_config *cfg, mppi_cb_handle **out);
+int mppi_cb_destroy(mppi_cb_handle *h);
+/* the nominal control sequence `U` [T, nu] (host) */
+int mppi_cb_set_nominal(mppi_cb_handle *h, const double *U);
+int mppi_cb_get_nominal(mppi_cb_handle *h, double *U);
+/* state: host [nx]; eps: device float [K, T, nu] or NULL (Philox); action_out: host [nu] */
+int mppi_cb_command(mppi_cb_handle *h, const double *state, const float *eps, int32_t shift_nominal_trajectory,
+                    double *action_out, void *stream);
+/* `cost_total` [K] and the weights `omega` [K] of the last command (either nullable) */
+int mppi_cb_get_costs(mppi_cb_handle *h, double *cost_total, double *omega);
+/* the callbacks themselves, batched: what = 0 `dynamics(states, actions, t)` -> [n, nx]; 1 `running_cost` -> [n] */
+int mppi_cb_eval(mppi_cb_handle *h, int32_t what, const double *states, const double *actions, int32_t t, int32_t n,
+                 double *out);
+/* the trajectory U drives from `state`: [T, nx] (the optimal trajectory of the callers' get_trajectories) */
+int mppi_cb_nominal_trajectory(mppi_cb_handle *h, const double *state, double *traj);
+
 #ifdef __cplusplus
 }
 #endif

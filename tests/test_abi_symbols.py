@@ -51,13 +51,16 @@ def test_config_struct_matches_header_size():
     import subprocess
     import tempfile
     from dnn_mppi_mpc_amd import _capi
-    src = '#include <stdio.h>\n#include "mppi_hip.h"\nint main(){printf("%zu %zu", sizeof(mppi_config), sizeof(mppi_stats));}'
+    src = ('#include <stdio.h>\n#include "mppi_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(mppi_config), sizeof(mppi_stats), '
+           'sizeof(mppi_cb_config));}')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
-        a, b = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+        a, b, cb = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     assert int(a) == C.sizeof(_capi.MppiConfig)
     assert int(b) == C.sizeof(_capi.MppiStats)
+    from dnn_mppi_mpc_amd import callback_mppi
+    assert int(cb) == C.sizeof(callback_mppi.MppiCbConfig)
 
 
 def test_no_cpu_fallback_without_gpu():
