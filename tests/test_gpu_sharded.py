@@ -75,3 +75,50 @@ def test_two_process_shards_equal_single_process(exchange):
         np.testing.assert_allclose(u_r, u_loop, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(x_r, x_loop, rtol=1e-9, atol=1e-12)
         assert it_r == 7
+
+
+def _nccl_worker(port, q):
+    """world_size 1 over the NCCL backend (= RCCL): the sharded controller takes the collective carrier
+    (`all_gather_into_tensor` on device tensors) exactly as N ranks on N GPUs would, with one rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import dnn_mppi_mpc_amd as pkg
+        from dnn_mppi_mpc_amd.distributed import exchange_partials
+        kw, lem = _kwargs(2048)
+        c = pkg.MPPIRacecarController(**kw, precision="f64", seed=5, process_group=dist.group.WORLD)
+        assert c._sharded and dist.get_backend(dist.group.WORLD) == "nccl"
+        us = [c._calc_control_input(lem[it].astype(np.float64))[1].copy() for it in range(3)]
+        c._engine.set_state(lem[3].astype(np.float64))
+        c.run_closed_loop_sharded(5)  # begin -> dist.all_gather_into_tensor (RCCL) -> end_async, per iteration
+        part = torch.arange(7, dtype=torch.float64, device="cuda")
+        gathered = exchange_partials(part, 1, dist.group.WORLD)
+        q.put((np.stack(us), c.u_prev.copy(), c._engine.get_state(), gathered.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collective_path_with_one_rank():
+    """`backend="nccl"` of distributed.exchange_partials / run_closed_loop_sharded executed on the GPU (RCCL needs one
+    GPU per rank, so one rank here; two ranks run it over gloo above): results equal the unsharded controller."""
+    import dnn_mppi_mpc_amd as pkg
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    us_r, u_r, x_r, g = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(g, np.arange(7.0))
+    kw, lem = _kwargs(2048)
+    one = pkg.MPPIRacecarController(**kw, precision="f64", seed=5)
+    us = np.stack([one._calc_control_input(lem[it].astype(np.float64))[1].copy() for it in range(3)])
+    one._engine.set_state(lem[3].astype(np.float64))
+    one._engine.run_closed_loop(5)
+    np.testing.assert_allclose(us_r, us, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(u_r, one._engine.get_u_prev(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(x_r, one._engine.get_state(), rtol=1e-9, atol=1e-12)
