@@ -1631,6 +1631,9 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             for (int i = tid; i < 2 * T; i += NT) rec[3 + i] = (double)(sh_u[i] * eta);  // W itself
             if (tid == 0) { rec[0] = (double)rho; rec[1] = (double)eta; rec[2] = (double)eta2; }
         }
+        // every wave's stores into the peers' buffers are acknowledged before the flags go up (the release store in
+        // exchange_flags is made by wave 0 alone: across a link it orders that wave's own stores only)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (!exchange_flags(F, peer_ptr, slot_off)) {  // a peer never arrived: nothing is updated
             if (tid == 0) {
                 res->status = STATUS_EXCHANGE_FAILED;

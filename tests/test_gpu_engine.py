@@ -52,7 +52,7 @@ def test_inkernel_sampler_equals_materialised_sampler():
         ua = a._calc_input_control(x0)[1].copy()
         ub = b._calc_input_control(x0)[1].copy()
         np.testing.assert_allclose(ua, ub, rtol=0, atol=1e-7)
-        np.testing.assert_allclose(a.sample_costs(), b.sample_costs(), rtol=1e-6)
+        np.testing.assert_allclose(a.sample_costs(), b.sample_costs(), rtol=1e-6, atol=1e-6)  # (costs near zero: absolute)
 
 
 @pytest.mark.parametrize("name", ["dd_c2_k4096_default", "dd_c2_k4096_moderate"])
