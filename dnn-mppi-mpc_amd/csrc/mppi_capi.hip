@@ -1117,10 +1117,28 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     long long batch = P.hyp ? 32 : (1LL << 62);
     while (done < target) {
         const long long todo = target - done < batch ? target - done : batch;
-        for (long long i = 0; i < todo; ++i) launch_slot<R>(h, P, F, s);
-        HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, (size_t)h->B * h->res_bytes, hipMemcpyDeviceToHost, s));
-        HIPCHECK(h, hipStreamSynchronize(s));
+        // The last slot of the batch writes its result straight into mapped host memory and publishes a sequence word
+        // the host polls (as mppi_step does): no copy launch and no stream synchronisation at the end of the call
+        // (14 -> 7 us of fixed cost per call).  Several agents per handle: one result per agent, copied as before.
+        const bool poll = h->poll && h->B == 1;
+        for (long long i = 0; i < todo; ++i) {
+            if (poll && i == todo - 1) {
+                FinalizeParams Fl = F;
+                Fl.res = h->res_mapped;
+                Fl.seq = ++h->seq;
+                launch_slot<R>(h, P, Fl, s);
+            } else {
+                launch_slot<R>(h, P, F, s);
+            }
+        }
         HIPCHECK(h, hipGetLastError());
+        if (poll) {
+            if (int rc = wait_result(h, h->seq, s)) return rc;
+        } else {
+            HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, (size_t)h->B * h->res_bytes, hipMemcpyDeviceToHost, s));
+            HIPCHECK(h, hipStreamSynchronize(s));
+            HIPCHECK(h, hipGetLastError());
+        }
         for (int a = 1; a < h->B; ++a) {  // an agent at the end of its path stops the batch like the single agent does
             const StepResult *ra =
                 reinterpret_cast<const StepResult *>(reinterpret_cast<const char *>(h->h_res) + (size_t)a * h->res_bytes);
