@@ -321,3 +321,36 @@ def test_exchange_api_errors():
     e.set_ref_path(mppi_oracle.generate_point_trajectory((0, 0), (1, 1), 10))
     # without a connected exchange the handle is an ordinary (sharded: use the split step) one
     assert e.lib.mppi_comm_handle_bytes() == 64
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_one_launch_index_resolution_and_its_fallback(precision):
+    """The sequential index resolved in one launch (per-call maps on 16 entry indices, fused_hyp) and its fallback: on a
+    densely sampled path a fast robot carries the index further than the table reaches within one iteration, so the
+    chain leaves it in some workgroup and the speculation rounds take over from there (rounds > 1); on a coarse path
+    the table suffices (rounds == 1).  Either way index, costs and controls equal the oracle's."""
+    import dnn_mppi_mpc_amd as pkg
+    seen = set()
+    for n_ref, speed in ((400, 4.0), (60, 1.0)):
+        rng = np.random.default_rng(n_ref)
+        K, T = 200, 40
+        kw = dd_case(rng, K, T, n_ref, 0)
+        kw.update(max_speed=speed + 1.0, delta_t=0.1, param_exploration=0.1)
+        u_in = np.column_stack([np.full(T, speed), rng.normal(0, 0.05, T)])
+        eps = philox.sample_epsilon(kw["sigma"], 5, 0, K, T)
+        o = mppi_oracle.DiffDriveOracle(**kw)
+        c = pkg.MPPIAlgorithms(**kw, precision=precision)
+        o.u_prev[:] = u_in
+        c.u_prev[:] = u_in
+        c._calc_epsilon = lambda *a, **k: eps
+        x0 = kw["ref_path"][0] + np.array([0.05, -0.03, 0.0])
+        for it in range(3):
+            ref = o.iteration(x0, eps.astype(np.float64))
+            u = c._calc_input_control(x0)[1]
+            assert c.prev_way_point_idx == ref["idx_after"], (n_ref, it)
+            seen.add(c.last_stats.rounds > 1)
+            tol = dict(rtol=1e-9, atol=1e-9) if precision == "f64" else dict(rtol=3e-4, atol=3e-4)
+            np.testing.assert_allclose(c.sample_costs(), ref["S"], **tol)
+            assert rmse(u, ref["u_returned"]) <= (1e-8 if precision == "f64" else 1e-4)
+            x0 = mppi_oracle.diffdrive_plant_step(x0, ref["u0_returned"], kw["delta_t"])
+    assert seen == {True, False}  # both the fallback and the pure one-launch resolution ran
