@@ -551,9 +551,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     }
     __syncthreads();
     STAMP(3);
-    R rho = sh_S[0];
-#pragma unroll
-    for (int w = 1; w < FUSED_WAVES; ++w) rho = fmin(rho, sh_S[w]);
+    // rho_b = min over the workgroup's 16 costs: lane w of a row reads sample w's, four DPP steps fold the row (every wave
+    // needs it: 16 reads + 15 minima per wave took a twelfth of the launch's VALU instructions)
+    static_assert(FUSED_WAVES == 16, "one DPP row of costs");
+    const R rho = wv::read_lane(wv::scan_incl_row<wv::OpMin>(sh_S[lane & 15]), 15);
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
     if (lane == 0) sh_e[wid] = e;
 #pragma unroll

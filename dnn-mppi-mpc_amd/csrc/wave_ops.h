@@ -67,6 +67,16 @@ template <typename Op, typename R> __device__ __forceinline__ R scan_incl_half(R
     return x;
 }
 
+// op over the 16 lanes of each DPP row (lane 15 / 31 / 47 / 63 of a row ends up with the row's result): 4 VALU ops
+template <typename Op, typename R> __device__ __forceinline__ R scan_incl_row(R x) {
+    const R id = Op::template identity<R>();
+    x = Op::apply(x, dpp<DPP_ROW_SHR1>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR2>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR4>(x, id));
+    x = Op::apply(x, dpp<DPP_ROW_SHR8>(x, id));
+    return x;
+}
+
 // SEG segments per wave (1: the whole wave, 2: its 32-lane halves)
 template <typename Op, int SEG, typename R> __device__ __forceinline__ R scan_incl_seg(R x) {
     return SEG == 2 ? scan_incl_half<Op>(x) : scan_incl<Op>(x);

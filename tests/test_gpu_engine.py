@@ -139,6 +139,36 @@ def test_config4_racecar_k65536_shard_against_c_oracle():
     assert rmse(u, ref["u_returned"]) <= 1e-4
 
 
+def test_config4_racecar_full_k65536_on_one_gpu_against_c_oracle():
+    """BASELINE config 4 at its full size on ONE handle (K=65536, T=75: what `bench.py --workload c4` runs at N=1, and the
+    union of the 8 shards) against the f32 C oracle; plus the size-independent property that the 8 contiguous shards'
+    softmin records merge to this handle's update (the exchange the ranks make, evaluated on the host in f64)."""
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    K, T = 65536, 75
+    kw = dict(ref_path=lem, horizon_step_T=T, number_of_samples_K=K,
+              obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), collision_safety_margin_rat=1.5,
+              visualize_optimal_traj=False, visualze_sampled_trajs=False)
+    sigma = np.array([[0.5, 0.0], [0.0, 0.1]])
+    eps = philox.sample_epsilon(sigma, 5, 0, K, T)
+    ref = c_oracle.RaceCarC(**kw).iteration(lem[0], eps)
+    import dnn_mppi_mpc_amd as pkg
+    c = pkg.MPPIRacecarController(**kw, seed=5)  # in-kernel Philox, iteration 0 = the tensor above
+    u = c._calc_control_input(lem[0])[1].copy()
+    S = c.sample_costs()
+    n_hit, n_hit_ref = np.rint(S / 1e10), np.rint(ref["S"] / 1e10)
+    assert np.mean(n_hit != n_hit_ref) < 2e-3  # an outline point within an f32 ulp of a circle may flip
+    same = n_hit == n_hit_ref
+    np.testing.assert_allclose(S[same], ref["S"][same], rtol=5e-5, atol=1e-2)
+    assert rmse(u, ref["u_returned"]) <= 1e-4
+    # the 8 shards' records {rho, eta, eta2, W} merged (f64) = the unsharded weighted noise
+    beta = 1.0 / 50.0
+    recs = [mppi_oracle.softmin_partial(S[r * 8192:(r + 1) * 8192], eps[r * 8192:(r + 1) * 8192], beta) for r in range(8)]
+    rho, eta, ess, w_eps = mppi_oracle.merge_partials(recs, beta)
+    wk = np.exp(-beta * (S - S.min()))
+    np.testing.assert_allclose(w_eps, np.einsum("k,ktd->td", wk / wk.sum(), eps.astype(np.float64)), rtol=1e-9, atol=1e-12)
+    assert abs(ess - c.last_stats.ess) <= 2e-3 * ess
+
+
 def test_shard_invariance_two_shards_one_gpu():
     """K split over two handles (k_offset 0 / K/2) and merged through the split-step ABI gives the
     single-handle result: exploit/explore split and Philox are keyed by the global sample index."""
