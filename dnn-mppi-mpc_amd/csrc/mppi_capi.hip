@@ -27,6 +27,7 @@ struct mppi_handle {
     void *d_partials2 = nullptr;    // second level for large K (records merged 64:1)
     void *d_heads = nullptr, *d_heads2 = nullptr;  // compact {rho, eta, eta2, 0} of d_partials / d_partials2
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
+    unsigned short *d_mlp16 = nullptr;  // the same as f16 hi / lo planes (k_rollout_mlp_h3)
     // one-launch resolution of the sequential waypoint index (HYP_R in mppi_kernels.h)
     bool hyp = false;
     void *d_hyp_rec = nullptr, *d_hyp_heads = nullptr, *d_hyp_S = nullptr;
@@ -272,7 +273,7 @@ extern "C" int mppi_destroy(mppi_handle *h) {
     if (h->xbuf) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
                     h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2, h->d_hyp_rec, h->d_hyp_heads,
-                    h->d_hyp_S, h->d_hyp_map, h->d_hyp_q};
+                    h->d_hyp_S, h->d_hyp_map, h->d_hyp_q, h->d_mlp16};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_res) hipHostFree(h->h_res);
@@ -355,6 +356,17 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
     for (int l = 0; l < 3; ++l) { h->mlp.w_h[l] = h->d_mlp + o_wh[l]; h->mlp.b_h[l] = h->d_mlp + o_bh[l]; }
     h->mlp.w_out = h->d_mlp + o_wo;
     for (int i = 0; i < 3; ++i) h->mlp.b_out[i] = b_out[i];
+    {   // the same weights as f16 (hi, lo) planes for k_rollout_mlp_h3
+        const size_t n_in16 = (size_t)2 * 16 * 1 * 64 * 8, n_h16 = (size_t)2 * 16 * 32 * 64 * 8, tot16 = n_in16 + 3 * n_h16;
+        std::vector<unsigned short> h16(tot16);
+        pack_linear_h3(w_in, 5, h16.data());
+        for (int l = 0; l < 3; ++l) pack_linear_h3(w_hidden[l], 512, h16.data() + n_in16 + (size_t)l * n_h16);
+        if (!h->d_mlp16) HIPCHECK(h, hipMalloc((void **)&h->d_mlp16, tot16 * sizeof(unsigned short)));
+        HIPCHECK(h, hipMemcpy(h->d_mlp16, h16.data(), tot16 * sizeof(unsigned short), hipMemcpyHostToDevice));
+        h->mlp.h3_w_in = h->d_mlp16;
+        for (int l = 0; l < 3; ++l) h->mlp.h3_w_h[l] = h->d_mlp16 + n_in16 + (size_t)l * n_h16;
+        h->mlp.use_h3 = getenv("MPPI_MLP_F32") ? 0 : 1;
+    }
     h->mlp_set = true;
     return MPPI_OK;
 }

@@ -158,6 +158,10 @@ struct MlpParams {
     const float *w_h[3], *b_h[3];    // Linear(512 -> 512) x 3: packed [16][64][64][4], bias [512]
     const float *w_out;              // Linear(512 -> 3): [3][512] as in the checkpoint
     float b_out[3];
+    // the f16-split kernel (k_rollout_mlp_h3): per layer two f16 planes (hi, then lo) in its fragment order
+    int use_h3;
+    const unsigned short *h3_w_in;   // [2][16][1][64][8]
+    const unsigned short *h3_w_h[3]; // [2][16][32][64][8]
 };
 
 struct VizParams {
@@ -214,6 +218,7 @@ int reduce_blocks(int K, int traj_per_block);
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s);
 int mlp_blocks(int K);
 void pack_linear(const float *w, int n_in, float *packed);  // host: [512][n_in] -> fragment order
+void pack_linear_h3(const float *w, int n_in, unsigned short *packed);  // host: -> two f16 planes in fragment order
 constexpr int MODEL_DIFF_MLP = 2;
 
 }  // namespace mppi

@@ -16,6 +16,8 @@
 // groups).  Per k-group: 2 LDS reads + 4 global loads feed 32 MFMAs (2048 cycles), so the loop is
 // MFMA-bound; the next group's operands are loaded before the current group's MFMAs issue.
 // 1 581 056 flop per trajectory-step.
+#include <string.h>
+
 #include "mppi_device.h"
 
 namespace mppi {
@@ -90,6 +92,113 @@ __device__ __forceinline__ void store_layer(float *act, const f32x16 (&acc)[2][4
     }
 }
 
+// ---- what the lanes of wave 0 (one lane = one sample of the tile) do around the network, shared by both kernels ----
+struct MlpLane {
+    float x, y, yaw, S;
+    int p;
+};
+
+// this sample's controls at step t: noise (Philox or the caller's tensor), perturb, clamp (:116-121)
+__device__ __forceinline__ void mlp_controls(const KParams<float> &P, unsigned iter, int k, int t, bool valid, bool exploit,
+                                             float &u0, float &u1, float &v0, float &v1) {
+    float e0 = 0.f, e1 = 0.f;
+    if (valid) {
+        if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
+        else {
+            const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
+            e0 = e.x;
+            e1 = e.y;
+        }
+    }
+    u0 = P.u[2 * t];
+    u1 = P.u[2 * t + 1];
+    v0 = exploit ? u0 + e0 : e0;  // mppi_differential_drive.py:116-119
+    v1 = exploit ? u1 + e1 : e1;
+    if (P.clamp_rollout) {
+        v0 = mf::clamp(v0, P.umax0);
+        v1 = mf::clamp(v1, P.umax1);
+    }
+}
+
+// Euler step of f + MLP (bullet_differential_drive_dnn.py:79-92), this call's waypoint index and costs
+__device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLanes<float> &obs, int c, int t, float r0, float r1,
+                                            float r2, float u0, float u1, float v0, float v1, MlpLane &L) {
+    const float *__restrict__ ref = P.ref;
+    float sn, cs;
+    mf::sincos_(L.yaw, sn, cs);
+    L.x = L.x + P.dt * (v0 * cs + r0);
+    L.y = L.y + P.dt * (v0 * sn + r1);
+    L.yaw = L.yaw + P.dt * (v1 + r2);
+    // waypoint index of this call: per-lane, so the sequential index threads through the sample's own
+    // calls in order by construction (mppi_differential_drive.py:228)
+    auto nearest = [&](int from) {
+        float best = dist2(ref, from, L.x, L.y);
+        int bj = 0;
+        for (int j = 1; j < P.window; ++j) {
+            const bool ok = from + j < P.n_ref;
+            const float d = ok ? dist2(ref, min(from + j, P.n_ref - 1), L.x, L.y) : INFINITY;
+            if (d < best) { best = d; bj = j; }
+        }
+        return from + bj;
+    };
+    const int idx = nearest(P.sequential ? L.p : c);
+    if (P.sequential) L.p = idx;
+    if (P.accumulate || t == P.T - 1) {
+        const bool hit = collided<false>(P, L.x, L.y, L.yaw, obs);
+        float st_c = tracking_cost<float, MODEL_DIFF>(P, P.ws, P.wrap_stage, idx, L.x, L.y, L.yaw, 0.f);
+        if (hit) st_c += P.penalty;
+        const float ctrl = (u0 * P.sinv[0] + u1 * P.sinv[2]) * v0 + (u0 * P.sinv[1] + u1 * P.sinv[3]) * v1;
+        const float stage = st_c + P.gamma * ctrl;
+        L.S = P.accumulate ? L.S + stage : stage;
+        if (t == P.T - 1) {
+            int idx_term = idx;
+            if (P.sequential) {  // the terminal call moves the index once more (:244)
+                L.p = nearest(L.p);
+                idx_term = L.p;
+            }
+            float term = tracking_cost<float, MODEL_DIFF>(P, P.wt, P.wrap_term, idx_term, L.x, L.y, L.yaw, 0.f);
+            if (hit) term += P.penalty;
+            L.S += term;
+        }
+    }
+}
+
+// this tile's softmin record {rho, eta, eta2, pad, W[T][2]} (wave 0)
+__device__ __forceinline__ void mlp_record(const KParams<float> &P, float *__restrict__ partials, unsigned iter, int k, int c,
+                                           bool valid, bool live, MlpLane &L, int lane) {
+    float S = L.S;
+    if (live) {
+        P.S[k] = S;
+        P.pout[k] = L.p;
+        if (P.sequential && L.p != c) atomicMin(&P.st->first_k, k);
+    } else if (valid) {
+        S = P.S[k];  // final from an earlier speculation round
+    }
+    const float Sm = valid ? S : INFINITY;
+    const float rho = wv::reduce<wv::OpMin>(Sm);
+    const float e = valid ? mf::exp_(-P.beta * (S - rho)) : 0.f;
+    const float eta = wv::reduce<wv::OpAdd>(e), eta2 = wv::reduce<wv::OpAdd>(e * e);
+    float *out = partials + (size_t)blockIdx.x * record_len(P.T, 4);
+    if (lane == 0) {
+        out[0] = rho; out[1] = eta; out[2] = eta2;
+        float *hd = P.heads + 4 * (size_t)blockIdx.x;  // the compact copy the merge kernels read
+        hd[0] = rho; hd[1] = eta; hd[2] = eta2; hd[3] = 0.f;
+    }
+    for (int t = 0; t < P.T; ++t) {  // second pass over this tile's noise rows (regenerated / re-read)
+        float e0 = 0.f, e1 = 0.f;
+        if (valid) {
+            if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
+            else {
+                const float2 ee = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
+                e0 = ee.x;
+                e1 = ee.y;
+            }
+        }
+        const float w0 = wv::reduce<wv::OpAdd>(e * e0), w1 = wv::reduce<wv::OpAdd>(e * e1);
+        if (lane == 0) { out[4 + 2 * t] = w0; out[4 + 2 * t + 1] = w1; }
+    }
+}
+
 __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams<float> P, const MlpParams Q,
                                                                     float *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -104,36 +213,17 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
     const bool valid = k < P.K, live = valid && k >= sv.k_start;
     const int c = sv.c;
     const unsigned iter = (unsigned)sv.iter;
-    const float *__restrict__ ref = P.ref;
 
     // sample state lives in the lanes of wave 0 (one lane = one sample of the tile)
-    float x = (float)sv.x0[0], y = (float)sv.x0[1], yaw = (float)sv.x0[2];
+    MlpLane L{(float)sv.x0[0], (float)sv.x0[1], (float)sv.x0[2], 0.f, c};
     const bool exploit = (k + P.k_offset) < P.n_exploit;
-    int p = c;
-    float S = 0.f;
     f32x16 acc[2][4];
 
     for (int t = 0; t < P.T; ++t) {
         float u0 = 0, u1 = 0, v0 = 0, v1 = 0;
         if (wid == 0) {
-            float e0 = 0.f, e1 = 0.f;
-            if (valid) {
-                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
-                else {
-                    const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
-                    e0 = e.x;
-                    e1 = e.y;
-                }
-            }
-            u0 = P.u[2 * t];
-            u1 = P.u[2 * t + 1];
-            v0 = exploit ? u0 + e0 : e0;  // mppi_differential_drive.py:116-119
-            v1 = exploit ? u1 + e1 : e1;
-            if (P.clamp_rollout) {
-                v0 = mf::clamp(v0, P.umax0);
-                v1 = mf::clamp(v1, P.umax1);
-            }
-            F4 z0 = {{x, y, yaw, v0}}, z1 = {{v1, 0.f, 0.f, 0.f}};
+            mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
+            F4 z0 = {{L.x, L.y, L.yaw, v0}}, z1 = {{v1, 0.f, 0.f, 0.f}};
             *reinterpret_cast<F4 *>(zbuf + lane * 8) = z0;
             *reinterpret_cast<F4 *>(zbuf + lane * 8 + 4) = z1;
         }
@@ -177,105 +267,323 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
                 r1 += o.v[1];
                 r2 += o.v[2];
             }
-            float sn, cs;
-            mf::sincos_(yaw, sn, cs);
-            x = x + P.dt * (v0 * cs + r0);  // Euler step of f + MLP (bullet_differential_drive_dnn.py:79-92)
-            y = y + P.dt * (v0 * sn + r1);
-            yaw = yaw + P.dt * (v1 + r2);
-            // waypoint index of this call: per-lane, so the sequential index threads through the sample's own
-            // calls in order by construction (mppi_differential_drive.py:228)
-            int idx;
-            const int from = P.sequential ? p : c;
-            {
-                float best = dist2(ref, from, x, y);
-                int bj = 0;
-                for (int j = 1; j < P.window; ++j) {
-                    const bool ok = from + j < P.n_ref;
-                    const float d = ok ? dist2(ref, min(from + j, P.n_ref - 1), x, y) : INFINITY;
-                    if (d < best) { best = d; bj = j; }
-                }
-                idx = from + bj;
-            }
-            if (P.sequential) p = idx;
-            if (P.accumulate || t == P.T - 1) {
-                const bool hit = collided<false>(P, x, y, yaw, obs);
-                float st_c = tracking_cost<float, MODEL_DIFF>(P, P.ws, P.wrap_stage, idx, x, y, yaw, 0.f);
-                if (hit) st_c += P.penalty;
-                const float ctrl = (u0 * P.sinv[0] + u1 * P.sinv[2]) * v0 + (u0 * P.sinv[1] + u1 * P.sinv[3]) * v1;
-                const float stage = st_c + P.gamma * ctrl;
-                S = P.accumulate ? S + stage : stage;
-                if (t == P.T - 1) {
-                    int idx_term = idx;
-                    if (P.sequential) {  // the terminal call moves the index once more (:244)
-                        float best = dist2(ref, p, x, y);
-                        int bj = 0;
-                        for (int j = 1; j < P.window; ++j) {
-                            const bool ok = p + j < P.n_ref;
-                            const float d = ok ? dist2(ref, min(p + j, P.n_ref - 1), x, y) : INFINITY;
-                            if (d < best) { best = d; bj = j; }
-                        }
-                        p = p + bj;
-                        idx_term = p;
-                    }
-                    float term = tracking_cost<float, MODEL_DIFF>(P, P.wt, P.wrap_term, idx_term, x, y, yaw, 0.f);
-                    if (hit) term += P.penalty;
-                    S += term;
-                }
-            }
+            mlp_advance(P, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
         }
         // zbuf / ypart are rewritten only after the next barrier sequence: wave 0 writes zbuf at the top of
         // the next step while the others wait at that step's first barrier
     }
+    if (wid == 0) mlp_record(P, partials, iter, k, c, valid, live, L, lane);
+}
 
-    // ---- this tile's softmin record {rho, eta, eta2, pad, W[T][2]} -------------------------------------
-    if (wid == 0) {
-        if (live) {
-            P.S[k] = S;
-            P.pout[k] = p;
-            if (P.sequential && p != c) atomicMin(&P.st->first_k, k);
-        } else if (valid) {
-            S = P.S[k];  // final from an earlier speculation round
+// ------------------------------------------------------------------------------------------
+// The same rollout on the f16 matrix pipe, 16 x the rate of the f32-input MFMA, at f32-like accuracy: every operand
+// is split into two f16 numbers, a = a_hi + a_lo (a_hi = f16(a), a_lo = f16(a - a_hi): 22 bits of significand, and
+// below f16's normal range an absolute resolution of 2^-25), and a b is taken as a_hi b_hi + a_hi b_lo + a_lo b_hi --
+// three `v_mfma_f32_32x32x16_f16` into the SAME f32 accumulator (every product of two f16 numbers is exact in f32).
+// Relative error of a dot product ~2^-21 against ~2^-23 of the f32 chain; the parity tests (u within 1e-4 RMSE of the
+// reference's class with the real checkpoint) hold with either kernel.  MPPI_MLP_F32=1 selects the f32-input kernel.
+//
+// Layout: activations as two f16 planes [64][520] in LDS (row pitch 1040 B: the 16-byte fragment reads of a 16-lane
+// group fall into distinct banks); lane l of a wave (r = l & 31, h = l >> 5) reads A[row r][k = 16 s + 8 h + 0..7] for
+// k-step s with one ds_read_b128 per plane and row tile.  Weights are packed on the host in fragment order
+// [column tile][k-step][lane][8] per plane, so B[k = 16 s + 8 h + j][col = 32 ct + r] = W[col][k] is one coalesced
+// 16-byte load per lane.  Per k-step and wave: 4 LDS reads + 8 global loads feed 24 MFMAs (768 cycles).
+// ------------------------------------------------------------------------------------------
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int H3_PITCH = 520, H3_ZPITCH = 24, H3_STEPS = MLP_H / 16;
+
+__device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// acc[pass][rt][c2] = A[64, 16 n_steps] @ W^T for this wave's 128 columns (column tile ct = 2 pass + c2); a_hi / a_lo:
+// the planes in LDS (row pitch `pitch` halfs).  Two passes of two column tiles each: the weights come from L2 (1 MB per
+// layer and workgroup, the same MB for every workgroup), at 8 KB per k-step and wave their latency is what the loop has
+// to cover -- so B runs THREE k-steps ahead in a ring of four register sets, and with two column tiles per pass that ring
+// is 64 VGPRs (with four it spilled); the activations come from LDS just in time, twice per layer.
+__device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Float16 *a_hi, const _Float16 *a_lo, int pitch,
+                                              const half8 *__restrict__ w_hi, const half8 *__restrict__ w_lo, int n_steps, int wid,
+                                              int lane) {
+    const int aoff = (lane & 31) * pitch + 8 * (lane >> 5);
+    struct FragA { half8 h[2], l[2]; };
+    struct FragB { half8 h[2], l[2]; };
+    auto load_a = [&](int s, FragA &f) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f.h[rt] = *reinterpret_cast<const half8 *>(a_hi + rt * 32 * pitch + aoff + 16 * s);
+            f.l[rt] = *reinterpret_cast<const half8 *>(a_lo + rt * 32 * pitch + aoff + 16 * s);
         }
-        const float Sm = valid ? S : INFINITY;
-        const float rho = wv::reduce<wv::OpMin>(Sm);
-        const float e = valid ? mf::exp_(-P.beta * (S - rho)) : 0.f;
-        const float eta = wv::reduce<wv::OpAdd>(e), eta2 = wv::reduce<wv::OpAdd>(e * e);
-        float *out = partials + (size_t)blockIdx.x * record_len(P.T, 4);
-        if (lane == 0) {
-            out[0] = rho; out[1] = eta; out[2] = eta2;
-            float *hd = P.heads + 4 * (size_t)blockIdx.x;  // the compact copy the merge kernels read
-            hd[0] = rho; hd[1] = eta; hd[2] = eta2; hd[3] = 0.f;
-        }
-        for (int t = 0; t < P.T; ++t) {  // second pass over this tile's noise rows (regenerated / re-read)
-            float e0 = 0.f, e1 = 0.f;
-            if (valid) {
-                if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
-                else {
-                    const float2 ee = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
-                    e0 = ee.x;
-                    e1 = ee.y;
-                }
+    };
+#define H3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        f32x16 (&ac)[2][2] = acc[pass];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ac[rt][c2][r] = 0.f;
+        const half8 *wl_hi = w_hi + (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;  // + (c2 * n_steps + s) * 64
+        const half8 *wl_lo = w_lo + (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;
+        auto load_b = [&](int s, FragB &f) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                f.h[c2] = wl_hi[((size_t)c2 * n_steps + s) * 64];
+                f.l[c2] = wl_lo[((size_t)c2 * n_steps + s) * 64];
             }
-            const float w0 = wv::reduce<wv::OpAdd>(e * e0), w1 = wv::reduce<wv::OpAdd>(e * e1);
-            if (lane == 0) { out[4 + 2 * t] = w0; out[4 + 2 * t + 1] = w1; }
+        };
+        // (the three terms as three sweeps over the four tiles: independent accumulators between two MFMAs on the same one)
+        auto mma = [&](const FragA &a, const FragB &b) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[rt], b.h[c2], ac[rt][c2], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[rt], b.l[c2], ac[rt][c2], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[rt], b.h[c2], ac[rt][c2], 0, 0, 0);
+        };
+        FragB b0, b1, b2, b3;
+        FragA a0, a1;
+        if (n_steps < 4) {  // the input layer: one k-step
+            for (int s = 0; s < n_steps; ++s) {
+                load_a(s, a0);
+                load_b(s, b0);
+                mma(a0, b0);
+            }
+            continue;
+        }
+        // (`sched_barrier`: the instruction scheduler would otherwise sink every load to just above its first use -- fewer
+        // live registers, and the prefetch gone)
+        load_b(0, b0);
+        load_b(1, b1);
+        load_b(2, b2);
+        load_a(0, a0);
+        H3_FENCE();
+#pragma unroll 1
+        for (int s = 0; s < n_steps; s += 4) {  // n_steps is a multiple of 4 (512 / 16 = 32)
+            load_b(s + 3, b3);
+            load_a(s + 1, a1);
+            H3_FENCE();
+            mma(a0, b0);
+            H3_FENCE();
+            if (s + 4 < n_steps) load_b(s + 4, b0);
+            load_a(s + 2, a0);
+            H3_FENCE();
+            mma(a1, b1);
+            H3_FENCE();
+            if (s + 5 < n_steps) load_b(s + 5, b1);
+            load_a(s + 3, a1);
+            H3_FENCE();
+            mma(a0, b2);
+            H3_FENCE();
+            if (s + 6 < n_steps) load_b(s + 6, b2);
+            if (s + 4 < n_steps) load_a(s + 4, a0);
+            H3_FENCE();
+            mma(a1, b3);
+            H3_FENCE();
+        }
+    }
+#undef H3_FENCE
+}
+
+// bias (+ tanh), split, then this wave's [64 x 128] slice of both planes back to LDS (C/D layout as store_layer).
+// The launch spends a third of its time here (one wave per SIMD: nothing else issues meanwhile), so two elements at a
+// time: packed f32 arithmetic for the bias, the tanh's linear parts and the residual, and `v_cvt_pkrtz_f16_f32` for
+// both conversions (the high part may round towards zero: the low part takes what is left, exactly).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+// Written in stages over the 16 registers of a tile (eight independent pairs per stage: with one wave per SIMD a chain
+// of dependent instructions -- exp, add, rcp, fma, convert, subtract, convert -- runs at its latency, 90 cycles per
+// element as the compiler first scheduled it, one pair after the other), and with four base addresses (plane x row tile)
+// plus immediate offsets for the 256 stores (their addresses had filled the register file and spilled into AGPRs).
+template <bool TANH>
+__device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[2][2][2], const float *bias,
+                                               int wid, int lane) {
+    const int lane_off = (4 * (lane >> 5)) * H3_PITCH + wid * 128 + (lane & 31);
+    _Float16 *const base[2][2] = {{a_hi + lane_off, a_hi + 32 * H3_PITCH + lane_off},
+                                  {a_lo + lane_off, a_lo + 32 * H3_PITCH + lane_off}};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float bn = bias[wid * 128 + ct * 32 + (lane & 31)];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{acc[ct >> 1][rt][ct & 1][2 * i], acc[ct >> 1][rt][ct & 1][2 * i + 1]} + bn;
+            if (TANH) {  // 1 - 2 / (exp(2x) + 1), exp(2x) = 2^(x * 2 log2(e))
+                f32x2 e[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2 a = v[i] * 2.8853900817779268f;
+                    e[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + 1.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = f32x2{__builtin_amdgcn_rcpf(e[i].x), __builtin_amdgcn_rcpf(e[i].y)};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 1.0f - 2.0f * e[i];
+            }
+            half2v hi[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hi[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[i].x, v[i].y));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = v[i] - f32x2{(float)hi[i].x, (float)hi[i].y};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lo[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[i].x, v[i].y));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // registers 2i, 2i + 1: rows (2i & 3) + 8 (2i >> 2) and the next one (+ rt, lane parts)
+                const int off = (((2 * i) & 3) + 8 * ((2 * i) >> 2)) * H3_PITCH + ct * 32;
+                base[0][rt][off] = hi[i].x;
+                base[0][rt][off + H3_PITCH] = hi[i].y;
+                base[1][rt][off] = lo[i].x;
+                base[1][rt][off + H3_PITCH] = lo[i].y;
+            }
         }
     }
 }
 
+#ifdef MPPI_STAMPS
+__device__ unsigned long long g_mlp_phase[16];
+#define PH(i)                                             \
+    do {                                                  \
+        const unsigned long long _n = clock64();          \
+        ph[i] += _n - ph_t;                               \
+        ph_t = _n;                                        \
+    } while (0)
+#else
+#define PH(i) \
+    do {      \
+    } while (0)
+#endif
+__global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KParams<float> P, const MlpParams Q,
+                                                                       float *__restrict__ partials) {
+#ifdef MPPI_STAMPS
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16 *a_hi = reinterpret_cast<_Float16 *>(smem);   // [64][520]
+    _Float16 *a_lo = a_hi + MLP_M * H3_PITCH;
+    _Float16 *z_hi = a_lo + MLP_M * H3_PITCH;              // [64][24] layer-0 input rows {x, y, yaw, v, w, 0 ...}: one k-step
+    _Float16 *z_lo = z_hi + MLP_M * H3_ZPITCH;
+    float *ypart = reinterpret_cast<float *>(z_lo + MLP_M * H3_ZPITCH);  // [4][64][4]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
+    const DevState sv = load_state(P, P.st);
+    const ObsLanes<float> obs = load_obstacles(P, lane);
+    if (k0 + MLP_M <= sv.k_start) return;
+    const bool valid = k < P.K, live = valid && k >= sv.k_start;
+    const int c = sv.c;
+    const unsigned iter = (unsigned)sv.iter;
+    MlpLane L{(float)sv.x0[0], (float)sv.x0[1], (float)sv.x0[2], 0.f, c};
+    const bool exploit = (k + P.k_offset) < P.n_exploit;
+    f32x16 acc[2][2][2];
+    if (wid == 0) {  // the padding of the layer-0 rows stays zero
+        for (int q = 0; q < H3_ZPITCH; ++q) { z_hi[lane * H3_ZPITCH + q] = (_Float16)0.f; z_lo[lane * H3_ZPITCH + q] = (_Float16)0.f; }
+    }
+    const half8 *wi_hi = reinterpret_cast<const half8 *>(Q.h3_w_in), *wi_lo = wi_hi + 16 * 64;
+
+    for (int t = 0; t < P.T; ++t) {
+        float u0 = 0, u1 = 0, v0 = 0, v1 = 0;
+        if (wid == 0) {
+            mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
+            const float z[5] = {L.x, L.y, L.yaw, v0, v1};
+#pragma unroll
+            for (int q = 0; q < 5; ++q) split_h3(z[q], z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
+        }
+        __syncthreads();
+        PH(0);
+        gemm_layer_h3(acc, z_hi, z_lo, H3_ZPITCH, wi_hi, wi_lo, 1, wid, lane);
+        PH(1);
+        store_layer_h3<false>(a_hi, a_lo, acc, Q.b_in, wid, lane);
+        PH(2);
+        __syncthreads();
+        PH(3);
+        for (int l = 0; l < 3; ++l) {
+            const half8 *wh = reinterpret_cast<const half8 *>(Q.h3_w_h[l]);
+            gemm_layer_h3(acc, a_hi, a_lo, H3_PITCH, wh, wh + (size_t)16 * H3_STEPS * 64, H3_STEPS, wid, lane);
+            PH(4);
+            __syncthreads();
+            PH(5);
+            store_layer_h3<true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
+            PH(6);
+            __syncthreads();
+            PH(7);
+        }
+        {   // out_layer in f32 on the vector unit: lane = sample, this wave's 128 of the 512 inputs
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            const _Float16 *hh = a_hi + lane * H3_PITCH + wid * 128, *hl = a_lo + lane * H3_PITCH + wid * 128;
+            const float *w = Q.w_out + wid * 128;
+#pragma unroll 4
+            for (int n = 0; n < 128; n += 8) {
+                const half8 vh = *reinterpret_cast<const half8 *>(hh + n), vl = *reinterpret_cast<const half8 *>(hl + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float hv = (float)vh[q] + (float)vl[q];
+                    s0 = fmaf(hv, w[n + q], s0);
+                    s1 = fmaf(hv, w[MLP_H + n + q], s1);
+                    s2 = fmaf(hv, w[2 * MLP_H + n + q], s2);
+                }
+            }
+            F4 o = {{s0, s1, s2, 0.f}};
+            *reinterpret_cast<F4 *>(ypart + (wid * MLP_M + lane) * 4) = o;
+        }
+        PH(8);
+        __syncthreads();
+        if (wid == 0) {
+            float r0 = Q.b_out[0], r1 = Q.b_out[1], r2 = Q.b_out[2];
+#pragma unroll
+            for (int w = 0; w < MLP_WAVES; ++w) {
+                const F4 o = *reinterpret_cast<const F4 *>(ypart + (w * MLP_M + lane) * 4);
+                r0 += o.v[0];
+                r1 += o.v[1];
+                r2 += o.v[2];
+            }
+            mlp_advance(P, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
+        }
+        PH(9);
+    }
+    if (wid == 0) mlp_record(P, partials, iter, k, c, valid, live, L, lane);
+#ifdef MPPI_STAMPS
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && wid == 1)
+        for (int i = 0; i < 10; ++i) g_mlp_phase[i] = ph[i];
+#endif
+}
+#undef PH
+#ifdef MPPI_STAMPS
+extern "C" int mppi_debug_mlp_phases(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_phase), sizeof(unsigned long long) * 10);
+}
+#endif
+
 int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
 
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
-    const size_t shmem = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4);
+    const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4);
+    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * MLP_WAVES * MLP_M * 4;
     // (the attribute belongs to the device's copy of the code object: one process may drive several GPUs)
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)shmem);
+                                  (int)shmem_f32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem_h3);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem, s, P, Q, (float *)partials);
+    if (Q.use_h3)
+        hipLaunchKernelGGL(k_rollout_mlp_h3, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials);
+    else
+        hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
 }
 
 // Host-side packing of a torch Linear weight [n_out = 512][n_in] into fragment order:
@@ -288,6 +596,66 @@ void pack_linear(const float *w, int n_in, float *packed) {
                 for (int s = 0; s < 4; ++s) {
                     const int n = 32 * ct + (lane & 31), kk = 8 * g + 4 * (lane >> 5) + s;
                     packed[(((size_t)ct * n_groups + g) * 64 + lane) * 4 + s] = kk < n_in ? w[(size_t)n * n_in + kk] : 0.f;
+                }
+}
+
+// IEEE binary16 of a float, round to nearest even (host; the kernels' v_cvt_f16_f32 does the same)
+static unsigned short f32_to_f16_bits(float f) {
+    unsigned int x;
+    memcpy(&x, &f, 4);
+    const unsigned int sign = (x >> 16) & 0x8000u;
+    const int exp = (int)((x >> 23) & 0xffu) - 127 + 15;
+    unsigned int man = x & 0x7fffffu;
+    if (((x >> 23) & 0xffu) == 0xffu) return (unsigned short)(sign | 0x7c00u | (man ? 0x200u : 0u));
+    if (exp >= 31) return (unsigned short)(sign | 0x7c00u);
+    if (exp <= 0) {  // subnormal or zero
+        if (exp < -10) return (unsigned short)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        unsigned int h = man >> shift;
+        const unsigned int rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (unsigned short)(sign | h);
+    }
+    unsigned int h = ((unsigned int)exp << 10) | (man >> 13);
+    const unsigned int rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;  // (a carry into the exponent is the right result)
+    return (unsigned short)(sign | h);
+}
+static float f16_bits_to_f32(unsigned short h) {
+    const unsigned int sign = (unsigned int)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    unsigned int x;
+    if (exp == 0) {
+        if (man == 0) x = sign;
+        else {
+            int e = -1;
+            unsigned int m = man;
+            do { ++e; m <<= 1; } while (!(m & 0x400u));
+            x = sign | ((unsigned int)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) x = sign | 0x7f800000u | (man << 13);
+    else x = sign | ((exp - 15 + 127) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// Host-side packing for k_rollout_mlp_h3: W [512][n_in] -> two f16 planes (hi, then lo) in fragment order
+// plane[ct (16)][s (n_steps)][lane (64)][j (8)] = W[32 ct + (lane & 31)][16 s + 8 (lane >> 5) + j]  (0 beyond n_in)
+void pack_linear_h3(const float *w, int n_in, unsigned short *packed) {
+    const int n_steps = (n_in + 15) / 16;
+    const size_t plane = (size_t)(MLP_H / 32) * n_steps * 64 * 8;
+    for (int ct = 0; ct < MLP_H / 32; ++ct)
+        for (int s = 0; s < n_steps; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * ct + (lane & 31), kk = 16 * s + 8 * (lane >> 5) + j;
+                    const float v = kk < n_in ? w[(size_t)n * n_in + kk] : 0.f;
+                    const unsigned short hi = f32_to_f16_bits(v);
+                    const unsigned short lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+                    const size_t o = (((size_t)ct * n_steps + s) * 64 + lane) * 8 + j;
+                    packed[o] = hi;
+                    packed[plane + o] = lo;
                 }
 }
 

@@ -618,13 +618,17 @@ def test_batched_agents_equal_separate_handles(monkeypatch, dual, model):
     assert ex.value.code == capi.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("kernel", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", gu.names("c5_"))
-def test_config5_checkpoint_against_patched_reference(name):
+def test_config5_checkpoint_against_patched_reference(monkeypatch, name, kernel):
     """BASELINE config 5 pinned through the reference itself (tests/golden/c5_*.npz: the reference's MPPIAlgorithms with
     `_state_transition` = x + dt (f + MLP), MLP = its MultiLayerPerceptron with saved_models/mlp_diff_300x100_3l.pth;
     oracle/gen_golden.py gen_config5).  The weights travel as plain arrays.  Tolerance: north star, u within 1e-4 RMSE;
     waypoint index equal; S to 1e-3 (f32 matrix cores through 3 x 512-wide layers and T recurrent steps)."""
     import dnn_mppi_mpc_amd as pkg
+    # both rollout kernels: operands split into two f16 numbers on the f16 matrix pipe (default), and f32-input MFMA
+    if kernel == "f32":
+        monkeypatch.setenv("MPPI_MLP_F32", "1")
     fx = gu.load(name)
     c = pkg.MPPIAlgorithms(**fx["meta"], learned_dynamics=gu.mlp_weights())
     c.u_prev[:] = fx["u_prev_in"]
