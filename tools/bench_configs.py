@@ -47,8 +47,14 @@ def report(name, K, T, eng, n, flop_per_step=None):
            "other_launches_us": 1e3 * (kms["reduce"] + kms["finalize"]),
            "algorithmic_GBs": alg / t_roll / 1e9, "hbm_frac": alg / t_roll / 8e12}
     if flop_per_step:
+        # algorithmic flop of the network per launch over the launch's duration.  The default kernel issues every product
+        # three times on the f16 matrix pipe (operands split into two f16 numbers each): its matrix-pipe load is 3 x that
+        # against the 2.5 PFLOP/s dense f16 peak; MPPI_MLP_F32=1 runs the f32-input MFMA kernel (157.3 TFLOP/s peak)
         out["TFLOPs"] = flop_per_step * K * T / t_roll / 1e12
-        out["mfma_f32_frac"] = out["TFLOPs"] / 157.3
+        if os.environ.get("MPPI_MLP_F32"):
+            out["kernel"], out["mfma_f32_frac"] = "k_rollout_mlp (f32-input MFMA)", out["TFLOPs"] / 157.3
+        else:
+            out["kernel"], out["mfma_f16_issue_frac"] = "k_rollout_mlp_h3 (f16 x 3)", 3.0 * out["TFLOPs"] / 2500.0
     print(json.dumps(out))
 
 
