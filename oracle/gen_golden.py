@@ -2,7 +2,9 @@
 
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
-    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py dd rc paths filters c5 vehicle ddtorch
+
+(every generator; each name selects one, no name = `dd rc paths`; all 28 committed fixtures regenerate bit for bit)
 
 It imports ``/root/reference/controllers/mppi_*.py`` unmodified, replaces the instance's
 ``_calc_epsilon`` with an injected noise tensor (recipe: SURVEY.md section 8c), spies on
