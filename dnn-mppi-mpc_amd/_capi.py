@@ -21,6 +21,7 @@ FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE, FILTER_TORCH = 0, 1, 2, 3
 OBSTACLE_NONE, OBSTACLE_CIRCLE, OBSTACLE_OUTLINE = 0, 1, 2
 OK, ERR_BAD_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_PATH_END, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 ERR_COMM = -8
+LAYOUT_FUSED, LAYOUT_DUAL, LAYOUT_PAIR, LAYOUT_KIND, LAYOUT_TWICE = 0, 1, 2, 3, 4  # mppi_get_rollout_layout
 
 
 class MppiConfig(C.Structure):
@@ -93,6 +94,7 @@ PROTOTYPES = {
     "mppi_enable_timing": (C.c_int, [_H, C.c_int32]),
     "mppi_set_rollout_repeats": (C.c_int, [_H, C.c_int32]),
     "mppi_get_counters": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "mppi_get_rollout_layout": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_step_device_x0": (C.c_int, [_H, C.c_void_p, C.c_void_p, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_eval_state_transition": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
     "mppi_eval_clamp": (C.c_int, [_H, _D, C.c_int32, _D]),

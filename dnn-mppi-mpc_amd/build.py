@@ -35,7 +35,7 @@ def source_id() -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -shared ... -> lib/libmppi_hip.so; returns its path."""
     if force or lib_is_stale():
-        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+        cmd = ["make", "-j4", "-C", CSRC] + (["-B"] if force else [])
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if verbose or res.returncode != 0:
             print(res.stdout)

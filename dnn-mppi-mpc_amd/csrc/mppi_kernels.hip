@@ -1995,10 +1995,12 @@ bool fused_supported(int T) { return T <= 128; }
 // it issues ~45 % fewer instructions per sample but halves the number of waves, and at K = 4096 the
 // rollout is latency-bound (2 waves per SIMD cannot cover the ~10-cycle dependent-issue latency; measured
 // 5.7 us against 5.0 us for one sample per wave).  MPPI_DUAL=0/1 overrides for experiments.
-static bool dual_layout(int K, int T) {
+// Several agents per launch (blockIdx.y) count together: what matters is the number of waves the LAUNCH brings (32 agents
+// of K = 4096: 6.7e10 -> 1.0e11 trajectory-steps/s with two samples per wave, 4 agents: 4.4e10 -> 5.6e10).
+static bool dual_layout(int K, int T, int n_agents) {
     if (T > 64) return false;
     if (const char *e = getenv("MPPI_DUAL")) return atoi(e) != 0;
-    return K >= 8192;
+    return (long long)K * n_agents >= 8192;
 }
 // 64 < T <= 128: one sample per wave, two steps per lane (k_rollout_dual<.., 1>) instead of two 64-step chunks
 static bool pair_layout(int T) {
@@ -2006,8 +2008,8 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
-int rollout_layout(int K, int T) {
-    const int kind = dual_layout(K, T) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
+int rollout_layout(int K, int T, int n_agents) {
+    const int kind = dual_layout(K, T, n_agents) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
     if (kind == LAYOUT_FUSED) return kind;
     // k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per
     // CU, and at most 512 records after halving (what k_finalize merges directly).  Beyond that the longer live

@@ -337,7 +337,10 @@ class Engine:
     def counters(self):
         out = (C.c_int64 * 3)()
         self._ck(self.lib.mppi_get_counters(self._h, out))
-        return {"iterations": out[0], "rollout_launches": out[1], "finalize_launches": out[2]}
+        layout = C.c_int32(-1)
+        if hasattr(self.lib, "mppi_get_rollout_layout"):  # (absent from an older diagnostic build under MPPI_LIB)
+            self._ck(self.lib.mppi_get_rollout_layout(self._h, C.byref(layout)))
+        return {"iterations": out[0], "rollout_launches": out[1], "finalize_launches": out[2], "rollout_layout": layout.value}
 
     def last_kernel_ms(self):
         out = (C.c_float * 4)()

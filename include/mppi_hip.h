@@ -298,6 +298,12 @@ int mppi_set_rollout_repeats(mppi_handle *h, int32_t n);
  * mode may take several of each (speculation rounds); bench.py divides a measured time by these. */
 int mppi_get_counters(mppi_handle *h, int64_t *out3);
 
+/* Which fused rollout kernel serves the handle (fixed at mppi_create from K x n_agents and T; diagnostic, for tests and
+ * profiles): low two bits 0 = one sample per wave, lanes over the horizon; 1 = two samples per wave, two steps per lane
+ * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128);
+ * +4 = every (half-)wave rolls out two samples in sequence.  -1: the handle does not use the fused kernels. */
+int mppi_get_rollout_layout(const mppi_handle *h, int32_t *layout);
+
 /*
  * `pytorch_mppi`-style MPPI with built-in dynamics / running-cost models: the callbacks the
  * reference's test/test_mppi.py, test/test_mppi_diff.py, test/test_mppi_diff_dyna.py and

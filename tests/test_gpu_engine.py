@@ -618,6 +618,35 @@ def test_batched_agents_equal_separate_handles(monkeypatch, dual, model):
     assert ex.value.code == capi.ERR_UNSUPPORTED
 
 
+def test_batched_agents_pick_the_layout_by_the_size_of_the_launch():
+    """Four agents of K = 2048 bring 8192 samples per launch: the batched handle takes the two-samples-per-wave layout on
+    its own, a single agent of K = 2048 the one-sample layout.  Same draws, same problem: f64 results agree to the
+    re-association of the prefix sums."""
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    B, K, T = 4, 2048, 50
+    ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100)
+    base = dict(model=capi.MODEL_DIFFDRIVE, T=T, delta_t=0.1, u_max=[5.0, 3.14], param_exploration=0.05, param_lambda=1.0,
+                param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01], stage_cost_weight=[5, 5, 10, 0],
+                terminal_cost_weight=[5, 5, 10, 0], search_window=20, filter_window=10, clamp_rollout=1,
+                waypoint_mode=capi.WAYPOINT_FROZEN, seed=41, precision=capi.PREC_F64)
+    x0 = np.stack([[0.2 * a, -0.1 * a, 0.1 * a] for a in range(B)])
+    batch = pkg.Engine(K=K, n_agents=B, **base)
+    batch.set_ref_path(ref)
+    batch.set_state(x0)
+    batch.run_closed_loop(3)
+    assert batch.counters()["rollout_layout"] & capi.LAYOUT_KIND == capi.LAYOUT_DUAL
+    for a in range(B):
+        one = pkg.Engine(K=K, noise_stream=a, **base)
+        one.set_ref_path(ref)
+        one.set_state(x0[a])
+        one.run_closed_loop(3)
+        assert one.counters()["rollout_layout"] & capi.LAYOUT_KIND == capi.LAYOUT_FUSED
+        np.testing.assert_allclose(batch.get_u_prev()[a], one.get_u_prev(), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(batch.get_state()[a], one.get_state(), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(batch.costs()[a], one.costs(), rtol=1e-9, atol=1e-11)
+
+
 @pytest.mark.parametrize("kernel", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", gu.names("c5_"))
 def test_config5_checkpoint_against_patched_reference(monkeypatch, name, kernel):
