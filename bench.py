@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: trajectory-steps/s of the MPPI iteration (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c4] [--no-cpu-baseline]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5] [--no-cpu-baseline] [--no-batched]
 
 A "step" is one closed-loop MPPI iteration (sample -> rollout -> cost -> softmin weight -> reduce ->
 filter -> shift, then the driver's plant advances the state).  Default workload `c2` = BASELINE config 2:
@@ -20,6 +20,13 @@ K_global = N*4096 samples and ONE exchange of {rho, eta, eta2, W[T,2]} per itera
 
 `--workload c4` = BASELINE config 4, the line north_star's ">= 6x at 8 GPUs" refers to: race car + 2 circular
 obstacles, K = 65536 samples x T = 75 in TOTAL, K/N per GPU (strong scaling), same exchange.
+
+`--workload c5` = BASELINE config 5: diff-drive with the learned residual dynamics (Linear 5-512, 3 x [Linear 512-512,
+tanh], Linear 512-3; train/train_diff_mlp.py:13-36) on the matrix cores, K = 32768 samples x T = 50 in TOTAL, K/N per GPU
+(strong scaling), frozen waypoint index; its `roofline` is the MFMA one.
+
+The default line also carries `batched_agents`: 32 independent config-2 problems in ONE handle (agents as a grid
+dimension) -- the launch size at which the chip, not the launch, is the limit.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream, over whole episodes
 of fixed length whatever --steps is (see `kernel_duration`); `cpu_baseline` is the plain-C oracle (test
@@ -40,6 +47,8 @@ sys.path.insert(0, ROOT)
 
 K_SAMPLES, HORIZON = 4096, 50
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: dense f16/bf16 matrix peak
+MLP_FLOP_PER_STEP = 1581056.0  # 2 x (5 x 512 + 3 x 512 x 512 + 512 x 3) per trajectory-step
 EPISODE = 1000   # tSim of the reference driver (controllers/mppi_differential_drive.py:396)
 TRAVERSE = 23    # iterations the robot needs from the head of the path to its goal (measured; reported separately)
 X_INIT = np.zeros(3)  # init_x, :394
@@ -72,6 +81,67 @@ def config4_kwargs(K=65536, T=75):
     return dict(ref_path=config4_path(), horizon_step_T=T, number_of_samples_K=K,
                 obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), collision_safety_margin_rat=1.5,
                 visualize_optimal_traj=False, visualze_sampled_trajs=False)
+
+
+def config5_kwargs(K=32768, T=50):
+    """BASELINE config 5: config 2's problem with x' = x + dt (f + MLP([x, v])) (test/bullet_differential_drive_dnn.py:79-92)."""
+    kw = config2_kwargs(K, T)
+    kw["param_exploration"] = 0.05
+    return kw
+
+
+def config5_weights():
+    """The reference checkpoint saved_models/mlp_diff_300x100_3l.pth as plain arrays (tests/golden, made by
+    oracle/gen_golden.py) when the file is there, else random weights of the same architecture."""
+    path = os.path.join(ROOT, "tests", "golden", "mlp_diff_300x100_3l_weights.npz")
+    if os.path.exists(path):
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}, "the reference checkpoint mlp_diff_300x100_3l (as arrays)"
+    rng = np.random.default_rng(0)
+    w = {"input_layer.weight": rng.normal(0, 0.3, (512, 5)), "input_layer.bias": rng.normal(0, 0.1, 512),
+         "out_layer.weight": rng.normal(0, 0.05, (3, 512)), "out_layer.bias": rng.normal(0, 0.01, 3)}
+    for i in range(3):
+        w[f"hidden_layer.{i}.weight"] = rng.normal(0, 0.04, (512, 512))
+        w[f"hidden_layer.{i}.bias"] = rng.normal(0, 0.1, 512)
+    return w, "random weights of the reference architecture"
+
+
+def batched_agents(n_agents=32, iters=400):
+    """SURVEY.md section 8 f1, many MPPI problems per launch: `n_agents` independent config-2 problems (own state, nominal
+    controls, waypoint index, noise stream) in ONE handle, agents as a grid dimension; frozen waypoint index (the
+    sequential one cannot be batched).  Returns the aggregate rate over whole closed-loop iterations."""
+    import torch
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    kw = config2_kwargs()
+    eng = pkg.Engine(model=capi.MODEL_DIFFDRIVE, K=K_SAMPLES, T=HORIZON, delta_t=kw["delta_t"],
+                     u_max=[kw["max_speed"], kw["max_omega"]], param_exploration=kw["param_exploration"],
+                     param_lambda=kw["param_lambda"], param_alpha=kw["param_alpha"], sigma=np.asarray(kw["sigma"]).reshape(-1),
+                     stage_cost_weight=list(kw["stage_cost_weight"]) + [0.0],
+                     terminal_cost_weight=list(kw["terminal_cost_weight"]) + [0.0], search_window=20, filter_window=10,
+                     clamp_rollout=1, clamp_u_after_update=0, waypoint_mode=capi.WAYPOINT_FROZEN, seed=5, n_agents=n_agents)
+    eng.set_ref_path(kw["ref_path"])
+    eng.set_state(np.zeros((n_agents, 3)))
+    eng.run_closed_loop(8)  # initialisation (code objects), as in the main line
+    torch.cuda.synchronize()
+
+    def timed(n):
+        t0 = time.perf_counter()
+        eng.run_closed_loop(n)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    dt = timed(EPISODE)       # a whole episode of the driver's run from the head of the path (with a frozen index the
+    dt_hold = timed(iters)    # agents take some 300 iterations to its end), then the hold phase alone
+    per_iter = n_agents * K_SAMPLES * HORIZON
+    alg = (16.0 * K_SAMPLES * HORIZON + 8.0 * K_SAMPLES) * n_agents
+    return {"agents": n_agents, "K_per_agent": K_SAMPLES, "T": HORIZON, "value": per_iter / dt, "unit": "trajectory-steps/s",
+            "us_per_iteration_all_agents": 1e6 * dt, "iterations": EPISODE,
+            "hold_phase": {"value": per_iter / dt_hold, "us_per_iteration_all_agents": 1e6 * dt_hold, "iterations": iters},
+            "algorithmic_GBs_over_whole_iterations": alg / dt / 1e9, "hbm_frac_over_whole_iterations": alg / dt / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_hold_phase": alg / dt_hold / 1e9 / HBM_PEAK_GBS,
+            "rollout_layout": eng.counters()["rollout_layout"],
+            "note": "one rollout launch + one finalize launch per iteration for all agents; algorithmic bytes as in `roofline` "
+                    "over the WHOLE iteration (serial tail included), so a lower bound on the rollout launch's own fraction"}
 
 
 def cpu_model():
@@ -149,11 +219,17 @@ def stamped_profile(name, build_id):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", choices=["c2", "c4"], default="c2")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true")
     args = ap.parse_args()
+    c5 = args.workload == "c5"
+    if args.steps is None:
+        args.steps = 40 if c5 else 2000  # (an iteration of config 5 takes milliseconds)
+    if args.warmup is None:
+        args.warmup = 5 if c5 else 200
 
     import torch
     import torch.distributed as dist
@@ -182,7 +258,14 @@ def main():
 
     import dnn_mppi_mpc_amd as pkg
     c4 = args.workload == "c4"
-    if c4:
+    if c5:
+        K_global, T, episode, traverse = 32768, 50, 1000, 0
+        K_local = pkg.distributed.shard_range(K_global, rank, world)[1]
+        x_init = X_INIT
+        weights, weights_src = config5_weights()
+        make = lambda: pkg.MPPIAlgorithms(**config5_kwargs(K_global, T), precision="f32", device=local_rank, seed=2024,
+                                          process_group=pg, waypoint_mode="frozen", learned_dynamics=weights)
+    elif c4:
         K_global, T, episode, traverse = 65536, 75, 100, 0  # the driver's loop runs over its 100 waypoints (:336)
         K_local = pkg.distributed.shard_range(K_global, rank, world)[1]
         x_init = config4_path()[0].astype(np.float64)
@@ -262,7 +345,7 @@ def main():
         #     kernel is launched twice wherever it is launched once, divided by the number of launches -- two events
         #     around the whole region, so no per-launch event overhead enters;
         # (b) per-launch event pairs with an empty-pair calibration (exclude dispatch): the cross-check and fallback.
-        n_kernel_iters = max(2 * episode, 2000)
+        n_kernel_iters = 20 if c5 else max(2 * episode, 2000)
         it0 = int(eng.counters()["iterations"])
 
         def kernel_duration(repeats):
@@ -305,7 +388,7 @@ def main():
 
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
-    if not sharded and not c4:
+    if not sharded and not c4 and not c5:
         from oracle import mppi_oracle
         import contextlib
         import io
@@ -346,7 +429,8 @@ def main():
             frac, t_roll = None, None
         traffic_d, traffic_src = stamped_profile("pmc_traffic", build_id)
         valu_d, valu_src = stamped_profile("pmc_valu", build_id)
-        kernel_name = ("k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>" if c4 else
+        kernel_name = ("k_rollout_mlp_h3 (operands split into two f16 numbers, three v_mfma_f32_32x32x16_f16 per product)" if c5 else
+                       "k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>" if c4 else
                        "k_rollout_fused<float, diffdrive, 1 chunk, single agent, PLAIN>")
         roof = {"bound": "valu_issue", "kernel": kernel_name,
                 "achieved": None if t_roll is None else alg_bytes / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -367,7 +451,25 @@ def main():
                         "waves per SIMD x 4 clocks / kernel_us, instruction counts from the PMC pass of this build "
                         "(null when no such pass is committed).  Averaged over whole episodes of the driver's run, "
                         "traversal included."}
-        if valu_d is not None and t_roll:
+        if c5:
+            # the learned-dynamics rollout is bound by the matrix pipe: algorithmic flop of the network per launch (SURVEY.md
+            # section 8d: 1 581 056 per trajectory-step) over the launch's duration, against the dense f16 peak.  The kernel
+            # issues every product three times (f32-like accuracy from f16 operands), which `mfma_issue_frac` counts.
+            f32_kernel = bool(os.environ.get("MPPI_MLP_F32"))
+            flop = MLP_FLOP_PER_STEP * K_local * T
+            peak = 157.3 if f32_kernel else MFMA_F16_PEAK_TFLOPS
+            ach = None if t_roll is None else flop / t_roll / 1e12
+            roof = {"bound": "mfma", "kernel": "k_rollout_mlp (f32-input MFMA)" if f32_kernel else kernel_name,
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
+                    "mfma_issue_frac": None if ach is None else (1.0 if f32_kernel else 3.0) * ach / peak,
+                    "traffic": None, "algorithmic_flop_per_launch": flop,
+                    "kernel_us": None if t_roll is None else 1e6 * t_roll, "kernel_us_method": method,
+                    "kernel_us_marginal": 1e6 * t_marg, "kernel_us_event_pair": 1e6 * ev_pair,
+                    "measured_over": {"iterations": n_kernel_iters, "rollout_launches": l1},
+                    "note": "achieved = algorithmic flop of the network per launch / the launch's duration; peak = dense "
+                            "f16 MFMA (the f32-input MFMA's 157.3 TFLOP/s with MPPI_MLP_F32=1); mfma_issue_frac counts "
+                            "the three MFMAs the kernel issues per product.  weights: " + weights_src}
+        elif valu_d is not None and t_roll:
             key = "config 4 shard" if c4 else "config 2"
             v = next((x for k, x in valu_d.items() if k.startswith(key)), None)
             if v is not None:
@@ -375,21 +477,26 @@ def main():
                 roof["valu_issue"] = {"valu_instructions_per_wave": v["per_wave"]["VALU"],
                                       "waves_per_simd": v["waves_per_simd"], "issue_us": v["valu_issue_us"],
                                       "source": valu_src}
-        if "valu_issue_frac" not in roof:
+        if not c5 and "valu_issue_frac" not in roof:
             roof["valu_issue_frac"] = None
             roof["valu_issue"] = {"source": valu_src}
-        out = {"metric": "trajectory-steps/sec (KxT/iter_time), " + ("race-car K=65536 T=75" if c4 else "diff-drive K=4096 T=50"),
+        out = {"metric": "trajectory-steps/sec (KxT/iter_time), " + ("diff-drive + learned MLP dynamics K=32768 T=50" if c5 else
+                                                                     "race-car K=65536 T=75" if c4 else "diff-drive K=4096 T=50"),
                "value": units * args.steps / dt,
                "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if c4 else "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": ("BASELINE config 4: race-car bicycle dynamics + 2 circular obstacles "
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if (c4 or c5) else "weak",
+               "vs_baseline": None, "dtype": "f32 (network products as three f16 MFMAs on split operands)" if c5 else "f32",
+               "data": "synthetic",
+               "config": {"workload": ("BASELINE config 5: differential-drive with learned residual dynamics (MLP 5-512-512-512-512-3 on "
+                                       "the matrix cores), K=32768 x T=50 in total, K/N per GPU, closed loop with the driver's plant "
+                                       "on the device") if c5 else
+                                      ("BASELINE config 4: race-car bicycle dynamics + 2 circular obstacles "
                                        "(mppi_race_car_obstacle defaults), K=65536 x T=75 in total, K/N per GPU, closed loop "
                                        "with the driver's plant on the device") if c4 else
                                       ("BASELINE config 2: differential-drive analytic dynamics, K=4096 x T=50 per GPU, "
                                        "reference __main__ parameters, closed loop with the driver's plant on the device"),
                           "K_per_gpu": K_local, "K_global": K_global, "T": T,
-                          "waypoint_mode": "frozen" + (" (K-sharded)" if sharded else "") if (sharded or c4)
+                          "waypoint_mode": "frozen" + (" (K-sharded)" if sharded else "") if (sharded or c4 or c5)
                                            else "sequential (reference-exact)",
                           "noise": "Philox4x32-10 in-kernel",
                           "timed_iterations": "closed-loop iterations %d..%d of the reference driver's run, which restarts "
@@ -405,7 +512,9 @@ def main():
                                     "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not c4 and not c5 and not args.no_batched:
+            out["batched_agents"] = batched_agents()
+        if world == 1 and not c4 and not c5 and not args.no_cpu_baseline:  # (the C restatement timed is config 2's)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if sharded:

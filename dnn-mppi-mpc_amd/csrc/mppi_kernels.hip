@@ -606,8 +606,11 @@ constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 // PLAIN: the noise is drawn in the kernel, the rollout clamps its controls and the yaw is wrapped in the costs exactly
 // when the model is the race car -- the reference's controllers as they come; those run-time switches become constants
 // (config 3: 16.2 -> 15.5 us per iteration in the hold phase, config 4 shard: 20.6 -> 20.2 us).
+// Batched agents (MULTI) bring thousands of workgroups per launch: the f32 diff-drive instantiation is held to 64 VGPRs (8
+// waves per SIMD) so that TWO workgroups share a CU and one's state wait, barrier and record stores run under the other's
+// arithmetic -- 32 agents of K = 4096: 1.0e11 -> 1.2e11 trajectory-steps/s.  (The race car would spill to scratch.)
 template <typename R, int MODEL, int SPW, bool MULTI, int SEQ, bool PLAIN>
-__global__ __launch_bounds__(64 * DUAL_WAVES) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
+__global__ __launch_bounds__(64 * DUAL_WAVES, (MULTI && sizeof(R) == 4 && MODEL == MODEL_DIFF) ? 8 : 1) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
     const int agent = MULTI ? (int)blockIdx.y : 0;  // several agents per launch (see k_rollout_fused)
     const bool use_philox = PLAIN || P.use_philox, clamp_rollout = PLAIN || P.clamp_rollout;
