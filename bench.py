@@ -380,9 +380,9 @@ def main():
     except pkg.MppiError as ex:
         # the peer-to-peer exchange lost a rank (every rank then fails within its timeout): measure again with the
         # one collective per iteration instead
-        if not sharded or ex.code != pkg._capi.ERR_COMM or os.environ.get("MPPI_EXCHANGE") == "collective":
+        if not sharded or ex.code != pkg._capi.ERR_COMM or os.environ.get("MPPI_EXCHANGE") in ("rccl", "collective"):
             raise
-        os.environ["MPPI_EXCHANGE"] = "collective"
+        os.environ["MPPI_EXCHANGE"] = "rccl"  # (falls through to the torch.distributed collective if RCCL cannot be set up)
         barrier()
         ctrl, eng, dt, idx_timed, k1, k2, n_kernel_iters, kms, phases = measure()
 
@@ -415,7 +415,7 @@ def main():
         method = "marginal (region with the kernel launched twice minus the plain region, per launch)"
         t_roll = t_marg
         ok = (l2 == 2 * l1 and t2x > t1x and t_marg >= 0.5 * ev_pair and t_marg <= period_per_launch)
-        if sharded and ctrl.exchange != "p2p":
+        if sharded and ctrl.exchange not in ("p2p", "rccl"):
             ok = False  # paced by the collective and the host: a repeated launch hides in the slack
         if not ok:
             t_roll = ev_pair
@@ -505,7 +505,8 @@ def main():
                           "waypoint_idx_at_end_of_timing": idx_timed,
                           "build_id": build_id,
                           "exchange": {"none": "none (one GPU)", "p2p": "peer-to-peer stores + flags inside k_finalize",
-                                       "collective": "one all-gather per iteration (RCCL)"}[ctrl.exchange]},
+                                       "rccl": "one ncclAllGather per iteration enqueued by the library (mppi_comm_init)",
+                                       "collective": "one all-gather per iteration (torch.distributed, RCCL)"}[ctrl.exchange]},
                "iter_latency_us": 1e6 * dt / args.steps,
                "phase_latency_us": None if phases is None else
                                    {"traverse (first %d iterations of an episode)" % traverse: 1e6 * phases["traverse"],

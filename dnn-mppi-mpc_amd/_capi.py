@@ -94,6 +94,9 @@ PROTOTYPES = {
     "mppi_enable_timing": (C.c_int, [_H, C.c_int32]),
     "mppi_set_rollout_repeats": (C.c_int, [_H, C.c_int32]),
     "mppi_get_counters": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "mppi_comm_unique_id_bytes": (C.c_int, []),
+    "mppi_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mppi_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     "mppi_get_rollout_layout": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_step_device_x0": (C.c_int, [_H, C.c_void_p, C.c_void_p, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_eval_state_transition": (C.c_int, [_H, _D, _D, C.c_int32, _D]),

@@ -76,23 +76,26 @@ class _ControllerBase:
         self._partial = None
         self._gathered = None
         self.last_stats = None
-        self.exchange = "none" if self._world == 1 else "collective"
-        if self._world > 1:
-            self._setup_peer_exchange()
+        self.exchange = "collective" if self._sharded else "none"
+        if self._sharded:
+            self._setup_exchange()
 
-    def _setup_peer_exchange(self):
-        """K sharded over several GPUs: wire the peer-to-peer exchange of the per-rank record (IPC-mapped
-        buffers + flags, include/mppi_hip.h `mppi_comm_*`) when every rank can; otherwise the iteration keeps
-        its one collective (RCCL all-gather).  ``MPPI_EXCHANGE=collective`` forces the latter."""
+    def _setup_exchange(self):
+        """K sharded over several GPUs: the carrier of the one exchange per iteration, agreed by all ranks --
+        "p2p": the per-rank record travels inside the finalize kernel (IPC-mapped buffers + flags, include/mppi_hip.h
+        `mppi_comm_connect`), no host call or collective launch per iteration; else "rccl": one ncclAllGather per
+        iteration enqueued by the library itself (`mppi_comm_init`, NCCL backend only: RCCL needs one GPU per rank);
+        else "collective": the split step around `torch.distributed.all_gather_into_tensor`.
+        ``MPPI_EXCHANGE=rccl|collective`` starts further down the list."""
         import os
 
         import torch
         import torch.distributed as dist
         want = os.environ.get("MPPI_EXCHANGE", "p2p").lower()
-        if want not in ("p2p", "collective"):
-            raise ValueError("MPPI_EXCHANGE must be 'p2p' or 'collective'")
+        if want not in ("p2p", "rccl", "collective"):
+            raise ValueError("MPPI_EXCHANGE must be 'p2p', 'rccl' or 'collective'")
         eng = self._engine
-        ok, handle = want == "p2p", b""
+        ok, handle = want == "p2p" and self._world > 1, b""
         if ok:
             try:
                 handle = eng.comm_export(self._world)
@@ -133,7 +136,32 @@ class _ControllerBase:
             ok = all_ok(ok)
         if ok:
             self.exchange = "p2p"
-        elif handle:
+            return
+        if handle:
+            eng.comm_close()
+        if want == "collective" or cpu:
+            return
+        # RCCL inside the library: every rank must be able to load librccl before any of them enters the (blocking)
+        # communicator set-up
+        uid = b""
+        try:
+            uid = eng.comm_unique_id()
+            ok = True
+        except Exception:  # noqa: BLE001
+            ok = False
+        if not all_ok(ok):
+            return
+        box = [uid if self._rank == 0 else None]
+        with torch.cuda.device(eng.cfg.device):
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self._pg, 0), group=self._pg)
+        try:
+            eng.comm_init(box[0], self._rank, self._world)
+            ok = True
+        except Exception:  # noqa: BLE001
+            ok = False
+        if all_ok(ok):
+            self.exchange = "rccl"
+        else:
             eng.comm_close()
 
     # -- mutable attributes of the reference ---------------------------------------------------------
@@ -252,7 +280,7 @@ class _ControllerBase:
         """K sharded over the ranks of ``process_group``: one all-gather per iteration, every rank finishes
         the iteration identically."""
         import torch
-        if self.exchange == "p2p":  # the finalize kernel exchanges the records itself
+        if self.exchange in ("p2p", "rccl"):  # the library exchanges the records itself
             return self._engine.step(x0, eps)
         part, _ = self._exchange_buffers()
         stream = torch.cuda.current_stream()
@@ -267,7 +295,7 @@ class _ControllerBase:
 
         import torch
         import torch.distributed as dist
-        if self.exchange == "p2p":  # nothing leaves the GPUs until the last iteration is done
+        if self.exchange in ("p2p", "rccl"):  # nothing leaves the GPUs until the last iteration is done
             _, st = self._engine.run_closed_loop(int(n_iters))
             u = self._engine.get_u_prev()
             self._u_host[...] = u

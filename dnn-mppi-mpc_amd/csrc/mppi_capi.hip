@@ -1,5 +1,6 @@
 // C ABI of libmppi_hip.so (include/mppi_hip.h): handle management, parameter packing and
 // the launch sequence of one MPPI iteration.  No algorithmic arithmetic happens on the host.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -15,6 +16,8 @@
 using namespace mppi;
 
 static thread_local std::string g_create_error;
+
+struct RcclUniqueId { char internal[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed by value to ncclCommInitRank
 
 struct mppi_handle {
     mppi_config cfg;
@@ -63,6 +66,10 @@ struct mppi_handle {
     char **d_xpeers = nullptr;       // device array [x_nranks]
     int *d_xerr = nullptr, *d_xok = nullptr;
     long long xseq = 0, x_timeout = 300000000LL;
+    // RCCL carrier inside the library (mppi_comm_init): communicator, this rank's record and the gathered records
+    void *rccl_comm = nullptr;
+    int rccl_rank = 0, rccl_nranks = 0;
+    double *d_rccl_part = nullptr, *d_rccl_gath = nullptr;
     long long n_rollout_launches = 0, n_finalize_launches = 0;  // mppi_get_counters
     std::string err;
 };
@@ -270,7 +277,7 @@ extern "C" int mppi_comm_close(mppi_handle *h);
 extern "C" int mppi_destroy(mppi_handle *h) {
     if (!h) return MPPI_OK;
     hipSetDevice(h->cfg.device);
-    if (h->xbuf) mppi_comm_close(h);
+    if (h->xbuf || h->rccl_comm) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
                     h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2, h->d_hyp_rec, h->d_hyp_heads,
                     h->d_hyp_S, h->d_hyp_map, h->d_hyp_q, h->d_mlp16};
@@ -740,11 +747,22 @@ static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
     return MPPI_OK;
 }
 
+// (the RCCL carrier of a K-sharded handle, further down)
+template <typename R>
+static int step_rccl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out, mppi_stats *stats,
+                     hipStream_t s);
+template <typename R>
+static int closed_loop_rccl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s);
+
 // x0: host (the observed state travels as kernel arguments) or, when null, x0_dev: device memory (a small kernel moves
 // it into the controller state and makes the x0 call)
 template <typename R>
 static int step_impl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
+    if (h->rccl_comm && h->x_nranks <= 1) {
+        if (!x0) FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_step_device_x0 on a handle with the RCCL carrier: pass the state from the host");
+        return step_rccl<R>(h, x0, eps, u_out, u0_out, stats, s);
+    }
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
     const bool by_args = x0 && h->idx_valid && h->by_args_ok;
@@ -817,24 +835,30 @@ extern "C" int mppi_partial_len(const mppi_handle *h, int32_t *n) {
     return MPPI_OK;
 }
 
+// rollout (-> reduce) -> merges down to this rank's ONE record {rho, eta, eta2, W[T][2]} in f64 at `partial` (device)
 template <typename R>
-static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
-    KParams<R> P = make_params<R>(h, eps);
-    const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
+static void launch_rank_record(mppi_handle *h, const KParams<R> &P, double beta, double *partial, hipStream_t s, bool tm) {
     const void *recs, *heads;
     int n_recs;
-    // closed loop on the device: the previous end_async already made the x0 call for the new state
-    if (x0 || !h->dev_loop_primed) launch_set_state<R>(P, x0, s);
-    h->dev_loop_primed = x0 == nullptr;
-    h->slot_timed = timing_on(h);
-    launch_front<R>(h, P, F.beta, s, &recs, &heads, &n_recs, h->slot_timed);
+    launch_front<R>(h, P, beta, s, &recs, &heads, &n_recs, tm);
     if (n_recs > MAX_FINAL_PARTS) {  // (k_merge takes 256 records per workgroup)
-        launch_merge<R>(recs, heads, n_recs, 64, h->cfg.T, F.beta, h->d_partials2, h->d_heads2, false, s);
+        launch_merge<R>(recs, heads, n_recs, 64, h->cfg.T, beta, h->d_partials2, h->d_heads2, false, s);
         recs = h->d_partials2;
         heads = h->d_heads2;
         n_recs = (n_recs + 63) / 64;
     }
-    launch_merge<R>(recs, heads, n_recs, n_recs, h->cfg.T, F.beta, partial, nullptr, true, s);  // this rank's record (f64)
+    launch_merge<R>(recs, heads, n_recs, n_recs, h->cfg.T, beta, partial, nullptr, true, s);
+}
+
+template <typename R>
+static int begin_impl(mppi_handle *h, const double *x0, const float *eps, double *partial, hipStream_t s) {
+    KParams<R> P = make_params<R>(h, eps);
+    const FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
+    // closed loop on the device: the previous end_async already made the x0 call for the new state
+    if (x0 || !h->dev_loop_primed) launch_set_state<R>(P, x0, s);
+    h->dev_loop_primed = x0 == nullptr;
+    h->slot_timed = timing_on(h);
+    launch_rank_record<R>(h, P, F.beta, partial, s, h->slot_timed);
     HIPCHECK(h, hipGetLastError());
     h->last_eps = eps;
     h->last_philox = eps == nullptr;
@@ -995,6 +1019,171 @@ extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *samp
 
 
 // ------------------------------------------------------------------------------------------
+// RCCL carrier of the same exchange inside the library (include/mppi_hip.h, mppi_comm_init):
+// one ncclAllGather of the per-rank record per iteration, enqueued on the caller's stream between the rollout and the
+// finalize launches -- no host code per iteration beyond the three enqueues.  librccl.so.1 is resolved at run time
+// (dlopen by soname: in a PyTorch-ROCm process that is the copy torch has already loaded), so the library has no
+// link-time dependency on RCCL and single-GPU users never load it.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+RcclApi &rccl_api() {
+    static RcclApi a;
+    static bool tried = false;
+    if (tried) return a;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (a.lib) break;
+    }
+    if (!a.lib) {
+        a.why = std::string("librccl.so.1 could not be loaded: ") + dlerror();
+        return a;
+    }
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) {
+        a.why = "librccl.so.1 lacks an expected symbol";
+        a.lib = nullptr;
+    }
+    return a;
+}
+}  // namespace
+
+static void rccl_release(mppi_handle *h) {
+    if (h->rccl_comm) rccl_api().CommDestroy(h->rccl_comm);
+    if (h->d_rccl_part) hipFree(h->d_rccl_part);
+    if (h->d_rccl_gath) hipFree(h->d_rccl_gath);
+    h->rccl_comm = nullptr;
+    h->d_rccl_part = h->d_rccl_gath = nullptr;
+    h->rccl_nranks = 0;
+}
+
+#define RCCLCHECK(h, call)                                                                                   \
+    do {                                                                                                     \
+        const int _r = (call);                                                                               \
+        if (_r != 0) FAIL(h, MPPI_ERR_COMM, "%s failed: %s", #call, rccl_api().GetErrorString(_r));          \
+    } while (0)
+
+extern "C" int mppi_comm_unique_id_bytes(void) { return (int)sizeof(RcclUniqueId); }
+
+extern "C" int mppi_comm_unique_id(void *id_out) {
+    if (!id_out) return MPPI_ERR_BAD_ARG;
+    RcclApi &a = rccl_api();
+    if (!a.lib) {
+        g_create_error = a.why;
+        return MPPI_ERR_COMM;
+    }
+    if (a.GetUniqueId(id_out) != 0) {
+        g_create_error = "ncclGetUniqueId failed";
+        return MPPI_ERR_COMM;
+    }
+    return MPPI_OK;
+}
+
+extern "C" int mppi_comm_init(mppi_handle *h, const void *unique_id, int32_t rank, int32_t nranks) {
+    if (!h || !unique_id) return MPPI_ERR_BAD_ARG;
+    SINGLE_AGENT_ONLY(h, "mppi_comm_init");
+    if (nranks < 1 || nranks > MAX_FINAL_PARTS || rank < 0 || rank >= nranks)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_init: rank %d of %d (1..%d ranks)", rank, nranks, MAX_FINAL_PARTS);
+    if (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "the exchange needs MPPI_WAYPOINT_FROZEN (no cross-sample waypoint state)");
+    RcclApi &a = rccl_api();
+    if (!a.lib) FAIL(h, MPPI_ERR_COMM, "mppi_comm_init: %s", a.why.c_str());
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    rccl_release(h);
+    RcclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    RCCLCHECK(h, a.CommInitRank(&h->rccl_comm, nranks, id, rank));
+    const size_t len = (size_t)partial_len(h->cfg.T);
+    HIPCHECK(h, hipMalloc((void **)&h->d_rccl_part, sizeof(double) * len));
+    HIPCHECK(h, hipMalloc((void **)&h->d_rccl_gath, sizeof(double) * len * nranks));
+    h->rccl_rank = rank;
+    h->rccl_nranks = nranks;
+    return MPPI_OK;
+}
+
+// One iteration on the stream with the collective in the middle: rollout -> this rank's record -> ncclAllGather ->
+// finalize over the gathered records (identical on every rank, so u stays replicated without a broadcast).
+template <typename R>
+static int rccl_iteration(mppi_handle *h, const KParams<R> &P, int plant, double *u0_trace_dev, hipStream_t s) {
+    const bool tm = timing_on(h);
+    const FinalizeParams F0 = make_finalize(h, h->d_partials, h->n_part, 0);
+    launch_rank_record<R>(h, P, F0.beta, h->d_rccl_part, s, tm);
+    RCCLCHECK(h, rccl_api().AllGather(h->d_rccl_part, h->d_rccl_gath, (size_t)partial_len(h->cfg.T), 8 /* ncclFloat64 */,
+                                      h->rccl_comm, s));
+    FinalizeParams F = make_finalize(h, h->d_rccl_gath, h->rccl_nranks, plant);
+    F.u0_trace = u0_trace_dev;
+    launch_back<R>(h, F, true, s, tm);
+    return MPPI_OK;
+}
+
+// outputs of the last finished iteration -> host (copy + synchronise; the collective paces the stream anyway)
+static int rccl_fetch(mppi_handle *h, double *u_out, double *u0_out, mppi_stats *stats, hipStream_t s) {
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(h, hipStreamSynchronize(s));
+    HIPCHECK(h, hipGetLastError());
+    h->idx = h->h_res->idx_after;
+    h->idx_valid = true;
+    fill_stats(h, stats);
+    if (h->h_res->status == STATUS_PATH_END) FAIL(h, MPPI_ERR_PATH_END, "[ERROR] Reached the end of the reference path.");
+    h->iter = h->h_res->iter;
+    const double *ru = reinterpret_cast<const double *>(h->h_res + 1);
+    if (u_out) memcpy(u_out, ru, sizeof(double) * 2 * h->cfg.T);
+    if (u0_out) { u0_out[0] = h->h_res->u0[0]; u0_out[1] = h->h_res->u0[1]; }
+    return MPPI_OK;
+}
+
+template <typename R>
+static int step_rccl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out, mppi_stats *stats,
+                     hipStream_t s) {
+    const KParams<R> P = make_params<R>(h, eps);
+    launch_set_state<R>(P, x0, s);
+    if (int rc = rccl_iteration<R>(h, P, 0, nullptr, s)) return rc;
+    h->dev_loop_primed = false;
+    h->last_eps = eps;
+    h->last_philox = eps == nullptr;
+    return rccl_fetch(h, u_out, u0_out, stats, s);
+}
+
+template <typename R>
+static int closed_loop_rccl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
+    const KParams<R> P = make_params<R>(h, nullptr);
+    double *trace = nullptr;
+    if (u0_trace) {
+        if (h->trace_cap < n_iters) {
+            if (h->d_trace) HIPCHECK(h, hipFree(h->d_trace));
+            h->d_trace = nullptr;
+            HIPCHECK(h, hipMalloc((void **)&h->d_trace, sizeof(double) * 2 * n_iters));
+            h->trace_cap = n_iters;
+        }
+        trace = h->d_trace - 2 * h->iter;  // the kernel indexes by the absolute iteration
+    }
+    if (!h->dev_loop_primed) launch_set_state<R>(P, nullptr, s);  // (see closed_loop_impl)
+    h->dev_loop_primed = false;
+    for (int i = 0; i < n_iters; ++i)
+        if (int rc = rccl_iteration<R>(h, P, 1, trace, s)) return rc;
+    h->last_eps = nullptr;
+    h->last_philox = true;
+    if (int rc = rccl_fetch(h, nullptr, nullptr, stats, s)) return rc;
+    if (u0_trace) HIPCHECK(h, hipMemcpy(u0_trace, h->d_trace, sizeof(double) * 2 * n_iters, hipMemcpyDeviceToHost));
+    h->dev_loop_primed = true;  // the last finalize made the next iteration's x0 call
+    return MPPI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Peer-to-peer exchange of the per-rank softmin record (include/mppi_hip.h, mppi_comm_*)
 // ------------------------------------------------------------------------------------------
 extern "C" int mppi_comm_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
@@ -1013,6 +1202,7 @@ extern "C" int mppi_comm_close(mppi_handle *h) {
     h->d_xerr = h->d_xok = nullptr;
     h->xbuf = nullptr;
     h->x_nranks = h->x_export_nranks = 0;
+    rccl_release(h);
     return MPPI_OK;
 }
 
@@ -1105,6 +1295,7 @@ extern "C" int mppi_comm_probe(mppi_handle *h, void *stream) {
 
 template <typename R>
 static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
+    if (h->rccl_comm && h->x_nranks <= 1) return closed_loop_rccl<R>(h, n_iters, u0_trace, stats, s);
     KParams<R> P = make_params<R>(h, nullptr);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 1);
     if (u0_trace) {

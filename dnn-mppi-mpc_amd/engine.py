@@ -233,6 +233,21 @@ class Engine:
     def comm_close(self):
         self._ck(self.lib.mppi_comm_close(self._h))
 
+    # -- the same exchange carried by RCCL inside the library (include/mppi_hip.h, mppi_comm_init) ----------
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the library (loads librccl.so.1 on first use); bytes for the other ranks."""
+        buf = C.create_string_buffer(self.lib.mppi_comm_unique_id_bytes())
+        rc = self.lib.mppi_comm_unique_id(buf)
+        if rc != capi.OK:
+            raise capi.MppiError(rc, (self.lib.mppi_last_error(None) or b"").decode() or "mppi_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        """ncclCommInitRank on the handle's device: collective, every rank calls it with rank 0's id.  From then on
+        ``step`` and ``run_closed_loop`` carry ONE ncclAllGather per iteration inside the library."""
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        self._ck(self.lib.mppi_comm_init(self._h, buf, int(rank), int(nranks)))
+
     def step_end(self, partials, nranks, stream=None):
         u, u0 = np.empty((self.T, 2)), np.empty(2)
         self._ck(self.lib.mppi_step_end(self._h, _dev_ptr(partials), int(nranks), _dp(u), _dp(u0),

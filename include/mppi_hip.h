@@ -228,6 +228,20 @@ int mppi_comm_connect(mppi_handle *h, int32_t rank, int32_t nranks, const void *
 int mppi_comm_probe(mppi_handle *h, void *stream);
 int mppi_comm_close(mppi_handle *h);
 
+/*
+ * The same exchange carried by RCCL INSIDE the library (`mppi_comm_init(h, ncclUniqueId, rank,
+ * nranks)`): rank 0 obtains an id with `mppi_comm_unique_id` (= ncclGetUniqueId, mppi_comm_unique_id_bytes() = 128 bytes),
+ * passes it to every rank over any host channel, and every rank calls `mppi_comm_init` (= ncclCommInitRank on the handle's
+ * device; collective, blocks until all ranks have called).  From then on mppi_step and mppi_run_closed_loop on that handle
+ * enqueue ONE ncclAllGather of the per-rank record (3 + 2T doubles) per iteration between the rollout and the finalize
+ * launches, on the caller's stream: a C caller needs no torch.distributed.  A peer-to-peer connection (mppi_comm_connect)
+ * takes precedence over it when both exist.  librccl.so.1 is loaded on first use (dlopen), not linked.  Needs
+ * MPPI_WAYPOINT_FROZEN; every rank must make the same sequence of calls; `mppi_comm_close` releases the communicator.
+ */
+int mppi_comm_unique_id_bytes(void);
+int mppi_comm_unique_id(void *id_out);
+int mppi_comm_init(mppi_handle *h, const void *unique_id, int32_t rank, int32_t nranks);
+
 /* S[K] of the last iteration (`S`, :103) and its weights (`_compute_weight`, :167-180); host doubles */
 int mppi_get_costs(mppi_handle *h, double *S);
 int mppi_get_weights(mppi_handle *h, double *w);

@@ -77,9 +77,11 @@ def test_two_process_shards_equal_single_process(exchange):
         assert it_r == 7
 
 
-def _nccl_worker(port, q):
+def _nccl_worker(port, q, exchange):
     """world_size 1 over the NCCL backend (= RCCL): the sharded controller takes the collective carrier
-    (`all_gather_into_tensor` on device tensors) exactly as N ranks on N GPUs would, with one rank."""
+    (`all_gather_into_tensor` on device tensors, or the library's own ncclAllGather after `mppi_comm_init`) exactly as N
+    ranks on N GPUs would, with one rank."""
+    os.environ["MPPI_EXCHANGE"] = exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -91,10 +93,10 @@ def _nccl_worker(port, q):
         from dnn_mppi_mpc_amd.distributed import exchange_partials
         kw, lem = _kwargs(2048)
         c = pkg.MPPIRacecarController(**kw, precision="f64", seed=5, process_group=dist.group.WORLD)
-        assert c._sharded and dist.get_backend(dist.group.WORLD) == "nccl"
+        assert c._sharded and dist.get_backend(dist.group.WORLD) == "nccl" and c.exchange == exchange
         us = [c._calc_control_input(lem[it].astype(np.float64))[1].copy() for it in range(3)]
         c._engine.set_state(lem[3].astype(np.float64))
-        c.run_closed_loop_sharded(5)  # begin -> dist.all_gather_into_tensor (RCCL) -> end_async, per iteration
+        c.run_closed_loop_sharded(5)  # rollout -> rank record -> all-gather (RCCL) -> finalize, per iteration
         part = torch.arange(7, dtype=torch.float64, device="cuda")
         gathered = exchange_partials(part, 1, dist.group.WORLD)
         q.put((np.stack(us), c.u_prev.copy(), c._engine.get_state(), gathered.cpu().numpy()))
@@ -102,13 +104,16 @@ def _nccl_worker(port, q):
         dist.destroy_process_group()
 
 
-def test_rccl_collective_path_with_one_rank():
-    """`backend="nccl"` of distributed.exchange_partials / run_closed_loop_sharded executed on the GPU (RCCL needs one
-    GPU per rank, so one rank here; two ranks run it over gloo above): results equal the unsharded controller."""
+@pytest.mark.parametrize("exchange", ["collective", "rccl"])
+def test_rccl_collective_path_with_one_rank(exchange):
+    """The two RCCL carriers executed on the GPU -- "collective": `backend="nccl"` of distributed.exchange_partials /
+    run_closed_loop_sharded; "rccl": the library's own communicator (`mppi_comm_unique_id` / `mppi_comm_init`) and the
+    ncclAllGather it enqueues per iteration.  RCCL needs one GPU per rank, so one rank here (two ranks run the split
+    step over gloo above): results equal the unsharded controller."""
     import dnn_mppi_mpc_amd as pkg
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q, exchange))
     p.start()
     us_r, u_r, x_r, g = q.get(timeout=240)
     p.join(timeout=60)
