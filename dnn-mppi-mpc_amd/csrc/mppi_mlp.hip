@@ -297,7 +297,12 @@ __device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-// acc[pass][rt][c2] = A[64, 16 n_steps] @ W^T for this wave's 128 columns (column tile ct = 2 pass + c2); a_hi / a_lo:
+// acc[pass][rt][c2] = (A[64, 16 n_steps] @ W^T)^T for this wave's 128 columns (column tile ct = 2 pass + c2), i.e. the MFMA's
+// "A" operand is the WEIGHT fragment and its "B" operand the activation fragment (both index a row / column by lane & 31
+// and eight reduction indices by lane >> 5, so the fragments serve either role as they are): in the 32 x 32 result a lane
+// then holds ONE sample (lane & 31 of row tile rt) and 16 output features in four runs of four consecutive ones -- which is
+// what the epilogue wants to write: four f16 numbers = one 8-byte LDS store instead of four 2-byte ones (the 2-byte stores
+// of the sample-per-register form held the LDS write port for a fifth of the launch).  a_hi / a_lo:
 // the planes in LDS (row pitch `pitch` halfs).  Two passes of two column tiles each: the weights come from L2 (1 MB per
 // layer and workgroup, the same MB for every workgroup), at 8 KB per k-step and wave their latency is what the loop has
 // to cover -- so B runs THREE k-steps ahead in a ring of four register sets, and with two column tiles per pass that ring
@@ -340,17 +345,17 @@ __device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Flo
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[rt], b.h[c2], ac[rt][c2], 0, 0, 0);
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.l[rt], ac[rt][c2], 0, 0, 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[rt], b.l[c2], ac[rt][c2], 0, 0, 0);
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[rt], b.h[c2], ac[rt][c2], 0, 0, 0);
+                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
         };
         FragB b0, b1, b2, b3;
         FragA a0, a1;
@@ -396,30 +401,40 @@ __device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Flo
 #undef H3_FENCE
 }
 
-// bias (+ tanh), split, then this wave's [64 x 128] slice of both planes back to LDS (C/D layout as store_layer).
-// The launch spends a third of its time here (one wave per SIMD: nothing else issues meanwhile), so two elements at a
+// bias (+ tanh), split, then this wave's [64 x 128] slice of both planes back to LDS.  Result layout (see gemm_layer_h3):
+// register r of tile (rt, ct) in lane l = sample 32 rt + (l & 31), feature 128 wid + 32 ct + (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// The launch spends a fifth of its time here (one wave per SIMD: nothing else issues meanwhile), so two elements at a
 // time: packed f32 arithmetic for the bias, the tanh's linear parts and the residual, and `v_cvt_pkrtz_f16_f32` for
-// both conversions (the high part may round towards zero: the low part takes what is left, exactly).
+// both conversions (the high part may round towards zero: the low part takes what is left, exactly) -- a converted
+// pair IS two consecutive features, two pairs one 8-byte store.
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
 // Written in stages over the 16 registers of a tile (eight independent pairs per stage: with one wave per SIMD a chain
 // of dependent instructions -- exp, add, rcp, fma, convert, subtract, convert -- runs at its latency, 90 cycles per
 // element as the compiler first scheduled it, one pair after the other), and with four base addresses (plane x row tile)
-// plus immediate offsets for the 256 stores (their addresses had filled the register file and spilled into AGPRs).
+// plus immediate offsets for the stores.
 template <bool TANH>
 __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[2][2][2], const float *bias,
                                                int wid, int lane) {
-    const int lane_off = (4 * (lane >> 5)) * H3_PITCH + wid * 128 + (lane & 31);
+    const int lane_off = (lane & 31) * H3_PITCH + wid * 128 + 4 * (lane >> 5);
     _Float16 *const base[2][2] = {{a_hi + lane_off, a_hi + 32 * H3_PITCH + lane_off},
                                   {a_lo + lane_off, a_lo + 32 * H3_PITCH + lane_off}};
+    const float *bl = bias + wid * 128 + 4 * (lane >> 5);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-        const float bn = bias[wid * 128 + ct * 32 + (lane & 31)];
+        f32x2 bn[8];  // the biases of this lane's 16 features of the tile: four aligned 16-byte loads
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const F4 b4 = *reinterpret_cast<const F4 *>(bl + ct * 32 + 8 * q);
+            bn[2 * q] = f32x2{b4.v[0], b4.v[1]};
+            bn[2 * q + 1] = f32x2{b4.v[2], b4.v[3]};
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             f32x2 v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = f32x2{acc[ct >> 1][rt][ct & 1][2 * i], acc[ct >> 1][rt][ct & 1][2 * i + 1]} + bn;
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{acc[ct >> 1][rt][ct & 1][2 * i], acc[ct >> 1][rt][ct & 1][2 * i + 1]} + bn[i];
             if (TANH) {  // 1 - 2 / (exp(2x) + 1), exp(2x) = 2^(x * 2 log2(e))
                 f32x2 e[8];
 #pragma unroll
@@ -440,12 +455,10 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) lo[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[i].x, v[i].y));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {  // registers 2i, 2i + 1: rows (2i & 3) + 8 (2i >> 2) and the next one (+ rt, lane parts)
-                const int off = (((2 * i) & 3) + 8 * ((2 * i) >> 2)) * H3_PITCH + ct * 32;
-                base[0][rt][off] = hi[i].x;
-                base[0][rt][off + H3_PITCH] = hi[i].y;
-                base[1][rt][off] = lo[i].x;
-                base[1][rt][off + H3_PITCH] = lo[i].y;
+            for (int q = 0; q < 4; ++q) {  // registers 4q .. 4q + 3: features 8q .. 8q + 3 (+ lane, tile and wave parts)
+                const int off = ct * 32 + 8 * q;
+                *reinterpret_cast<half4v *>(base[0][rt] + off) = half4v{hi[2 * q].x, hi[2 * q].y, hi[2 * q + 1].x, hi[2 * q + 1].y};
+                *reinterpret_cast<half4v *>(base[1][rt] + off) = half4v{lo[2 * q].x, lo[2 * q].y, lo[2 * q + 1].x, lo[2 * q + 1].y};
             }
         }
     }
