@@ -23,8 +23,25 @@
 namespace mppi {
 
 constexpr int MLP_M = 64, MLP_H = 512, MLP_PITCH = 516, MLP_WAVES = 4, MLP_GROUPS = MLP_H / 8;
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 struct alignas(16) F4 { float v[4]; };
+
+// Wave 0 searches the nearest waypoint of 64 samples every step while the other waves wait for it: the path (x, y, yaw, v
+// per waypoint) is copied to LDS once per launch when it fits the 16 KB left beside the activations, so the search reads
+// LDS instead of walking global memory (20 dependent loads per call, 5 % of the launch).
+constexpr int MLP_REF_LDS_MAX = 1024;
+
+// the path in LDS (returns the parameter block the per-sample code should use)
+__device__ __forceinline__ KParams<float> mlp_stage_path(const KParams<float> &P, float *ref_lds) {
+    KParams<float> PL = P;
+    if (P.n_ref <= MLP_REF_LDS_MAX) {
+        for (int i = threadIdx.x; i < P.n_ref; i += blockDim.x)
+            reinterpret_cast<F4 *>(ref_lds)[i] = reinterpret_cast<const F4 *>(P.ref)[i];
+        PL.ref = ref_lds;  // (first read behind the first workgroup barrier of the step loop)
+    }
+    return PL;
+}
 
 __device__ __forceinline__ float fast_tanh(float x) {  // 1 - 2 / (exp(2x) + 1): abs error ~2e-7
     const float e = __expf(2.0f * x);
@@ -134,6 +151,7 @@ __device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLa
     auto nearest = [&](int from) {
         float best = dist2(ref, from, L.x, L.y);
         int bj = 0;
+#pragma unroll 4
         for (int j = 1; j < P.window; ++j) {
             const bool ok = from + j < P.n_ref;
             const float d = ok ? dist2(ref, min(from + j, P.n_ref - 1), L.x, L.y) : INFINITY;
@@ -205,8 +223,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
     float *act = smem;                       // [64][516]
     float *zbuf = act + MLP_M * MLP_PITCH;   // [64][8]   layer-0 input rows {x, y, yaw, v, w, 0, 0, 0}
     float *ypart = zbuf + MLP_M * 8;         // [4][64][4] partial outputs of the last Linear per wave
+    float *ref_lds = ypart + MLP_WAVES * MLP_M * 4;  // [n_ref][4] when the path fits
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
+    const KParams<float> PL = mlp_stage_path(P, ref_lds);
     const DevState sv = load_state(P, P.st);
     const ObsLanes<float> obs = load_obstacles(P, lane);
     if (k0 + MLP_M <= sv.k_start) return;  // every sample of the tile is final: its record stands
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
                 r1 += o.v[1];
                 r2 += o.v[2];
             }
-            mlp_advance(P, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
+            mlp_advance(PL, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
         }
         // zbuf / ypart are rewritten only after the next barrier sequence: wave 0 writes zbuf at the top of
         // the next step while the others wait at that step's first barrier
@@ -414,9 +434,13 @@ using half4v = __attribute__((ext_vector_type(4))) _Float16;
 // of dependent instructions -- exp, add, rcp, fma, convert, subtract, convert -- runs at its latency, 90 cycles per
 // element as the compiler first scheduled it, one pair after the other), and with four base addresses (plane x row tile)
 // plus immediate offsets for the stores.
-template <bool TANH>
+// LAST (the third hidden layer): its activations feed only the 512 -> 3 output layer, so they are not split or stored at
+// all -- every lane multiplies its 64 features of a sample by the output weights as they leave the tanh (f32, `yo[rt][j]`),
+// and the caller adds up the two lane halves and the four waves.  (Reading them back from LDS on the vector unit took 6 %
+// of the launch, splitting and storing them another 2 %.)
+template <bool TANH, bool LAST = false>
 __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[2][2][2], const float *bias,
-                                               int wid, int lane) {
+                                               int wid, int lane, const float *w_out = nullptr, float (*yo)[3] = nullptr) {
     const int lane_off = (lane & 31) * H3_PITCH + wid * 128 + 4 * (lane >> 5);
     _Float16 *const base[2][2] = {{a_hi + lane_off, a_hi + 32 * H3_PITCH + lane_off},
                                   {a_lo + lane_off, a_lo + 32 * H3_PITCH + lane_off}};
@@ -429,6 +453,14 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
             const F4 b4 = *reinterpret_cast<const F4 *>(bl + ct * 32 + 8 * q);
             bn[2 * q] = f32x2{b4.v[0], b4.v[1]};
             bn[2 * q + 1] = f32x2{b4.v[2], b4.v[3]};
+        }
+        F4 wo[3][4];  // LAST: the output layer's weights of the same 16 features, requested before the tanh arithmetic
+        if (LAST) {
+            const float *wl = w_out + wid * 128 + 4 * (lane >> 5) + ct * 32;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wo[j][q] = *reinterpret_cast<const F4 *>(wl + j * MLP_H + 8 * q);
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -446,6 +478,17 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
                 for (int i = 0; i < 8; ++i) e[i] = f32x2{__builtin_amdgcn_rcpf(e[i].x), __builtin_amdgcn_rcpf(e[i].y)};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = 1.0f - 2.0f * e[i];
+            }
+            if (LAST) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x2 a = f32x2{0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        a = a + v[2 * q] * f32x2{wo[j][q].v[0], wo[j][q].v[1]} + v[2 * q + 1] * f32x2{wo[j][q].v[2], wo[j][q].v[3]};
+                    yo[rt][j] += a.x + a.y;
+                }
+                continue;
             }
             half2v hi[8], lo[8];
 #pragma unroll
@@ -488,8 +531,10 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     _Float16 *z_hi = a_lo + MLP_M * H3_PITCH;              // [64][24] layer-0 input rows {x, y, yaw, v, w, 0 ...}: one k-step
     _Float16 *z_lo = z_hi + MLP_M * H3_ZPITCH;
     float *ypart = reinterpret_cast<float *>(z_lo + MLP_M * H3_ZPITCH);  // [4][64][4]
+    float *ref_lds = ypart + MLP_WAVES * MLP_M * 4;                     // [n_ref][4] when the path fits
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
+    const KParams<float> PL = mlp_stage_path(P, ref_lds);
     const DevState sv = load_state(P, P.st);
     const ObsLanes<float> obs = load_obstacles(P, lane);
     if (k0 + MLP_M <= sv.k_start) return;
@@ -520,7 +565,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
         PH(2);
         __syncthreads();
         PH(3);
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < 2; ++l) {
             const half8 *wh = reinterpret_cast<const half8 *>(Q.h3_w_h[l]);
             gemm_layer_h3(acc, a_hi, a_lo, H3_PITCH, wh, wh + (size_t)16 * H3_STEPS * 64, H3_STEPS, wid, lane);
             PH(4);
@@ -531,23 +576,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             __syncthreads();
             PH(7);
         }
-        {   // out_layer in f32 on the vector unit: lane = sample, this wave's 128 of the 512 inputs
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            const _Float16 *hh = a_hi + lane * H3_PITCH + wid * 128, *hl = a_lo + lane * H3_PITCH + wid * 128;
-            const float *w = Q.w_out + wid * 128;
-#pragma unroll 4
-            for (int n = 0; n < 128; n += 8) {
-                const half8 vh = *reinterpret_cast<const half8 *>(hh + n), vl = *reinterpret_cast<const half8 *>(hl + n);
+        {   // the third hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's 128 of the 512 inputs
+            const half8 *wh = reinterpret_cast<const half8 *>(Q.h3_w_h[2]);
+            gemm_layer_h3(acc, a_hi, a_lo, H3_PITCH, wh, wh + (size_t)16 * H3_STEPS * 64, H3_STEPS, wid, lane);
+            PH(4);
+            float yo[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            store_layer_h3<true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float hv = (float)vh[q] + (float)vl[q];
-                    s0 = fmaf(hv, w[n + q], s0);
-                    s1 = fmaf(hv, w[MLP_H + n + q], s1);
-                    s2 = fmaf(hv, w[2 * MLP_H + n + q], s2);
-                }
+            for (int rt = 0; rt < 2; ++rt) {  // the two lane halves hold the two halves of a sample's features
+                F4 o;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o.v[j] = yo[rt][j] + __shfl_xor(yo[rt][j], 32);
+                o.v[3] = 0.f;
+                if (lane < 32) *reinterpret_cast<F4 *>(ypart + (wid * MLP_M + rt * 32 + lane) * 4) = o;
             }
-            F4 o = {{s0, s1, s2, 0.f}};
-            *reinterpret_cast<F4 *>(ypart + (wid * MLP_M + lane) * 4) = o;
         }
         PH(8);
         __syncthreads();
@@ -560,7 +602,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
                 r1 += o.v[1];
                 r2 += o.v[2];
             }
-            mlp_advance(P, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
+            mlp_advance(PL, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
         }
         PH(9);
     }
@@ -580,8 +622,9 @@ extern "C" int mppi_debug_mlp_phases(unsigned long long *out) {
 int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
 
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
-    const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4);
-    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * MLP_WAVES * MLP_M * 4;
+    const size_t ref_lds = sizeof(float) * 4 * MLP_REF_LDS_MAX;  // the path (mlp_stage_path)
+    const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4) + ref_lds;
+    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * MLP_WAVES * MLP_M * 4 + ref_lds;
     // (the attribute belongs to the device's copy of the code object: one process may drive several GPUs)
     static bool attr_set[64] = {};
     int dev = 0;
