@@ -327,101 +327,159 @@ __device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
 // layer and workgroup, the same MB for every workgroup), at 8 KB per k-step and wave their latency is what the loop has
 // to cover -- so B runs THREE k-steps ahead in a ring of four register sets, and with two column tiles per pass that ring
 // is 64 VGPRs (with four it spilled); the activations come from LDS just in time, twice per layer.
-__device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Float16 *a_hi, const _Float16 *a_lo, int pitch,
-                                              const half8 *__restrict__ w_hi, const half8 *__restrict__ w_lo, int n_steps, int wid,
-                                              int lane) {
+//
+// The weight stream does not stop between the two passes of a layer: the last trip of the first pass requests the first
+// three k-steps of the second into the ring sets it has just used up (an L2 round trip waited for at the top of every
+// pass before).  Across layers the ring is NOT kept: live through the epilogue it pushed the kernel into scratch spills
+// (8.3 against 6.8 ms); a layer requests its first k-steps at its top.
+struct H3FragA { half8 h[2], l[2]; };
+struct H3FragB { half8 h[2], l[2]; };
+struct H3Ring { H3FragB b0, b1, b2; };  // k-steps 0, 1, 2 of the pass about to run
+
+// this lane's view of the two column tiles of (layer `w`, pass): + (c2 * n_steps + s) * 64
+struct H3Pass { const half8 *hi, *lo; };
+__device__ __forceinline__ H3Pass h3_pass(const unsigned short *layer, int n_steps, int wid, int pass, int lane) {
+    const half8 *w = reinterpret_cast<const half8 *>(layer);
+    const size_t off = (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;
+    return H3Pass{w + off, w + (size_t)16 * n_steps * 64 + off};
+}
+__device__ __forceinline__ void h3_load_b(const H3Pass &w, int n_steps, int s, H3FragB &f) {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        f.h[c2] = w.hi[((size_t)c2 * n_steps + s) * 64];
+        f.l[c2] = w.lo[((size_t)c2 * n_steps + s) * 64];
+    }
+}
+__device__ __forceinline__ void h3_prime(const H3Pass &w, int n_steps, H3Ring &r) {
+    h3_load_b(w, n_steps, 0, r.b0);
+    h3_load_b(w, n_steps, 1, r.b1);
+    h3_load_b(w, n_steps, 2, r.b2);
+}
+// (the three terms as three sweeps over the four tiles: independent accumulators between two MFMAs on the same one)
+__device__ __forceinline__ void h3_mma(f32x16 (&ac)[2][2], const H3FragA &a, const H3FragB &b) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.l[rt], ac[rt][c2], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
+}
+__device__ __forceinline__ void h3_zero(f32x16 (&ac)[2][2]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ac[rt][c2][r] = 0.f;
+}
+
+// one pass (two column tiles) of a 512-wide hidden layer: `ring` holds its k-steps 0..2 on entry and (HAS_NEXT) those of
+// `next` on exit
+template <bool HAS_NEXT>
+__device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 *a_hi, const _Float16 *a_lo, const H3Pass &w,
+                                             const H3Pass &next, H3Ring &ring, int lane) {
+    constexpr int n_steps = H3_STEPS, pitch = H3_PITCH;
     const int aoff = (lane & 31) * pitch + 8 * (lane >> 5);
-    struct FragA { half8 h[2], l[2]; };
-    struct FragB { half8 h[2], l[2]; };
-    auto load_a = [&](int s, FragA &f) {
+    auto load_a = [&](int s, H3FragA &f) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             f.h[rt] = *reinterpret_cast<const half8 *>(a_hi + rt * 32 * pitch + aoff + 16 * s);
             f.l[rt] = *reinterpret_cast<const half8 *>(a_lo + rt * 32 * pitch + aoff + 16 * s);
         }
     };
+    // (`sched_barrier`: the instruction scheduler would otherwise sink every load to just above its first use -- fewer
+    // live registers, and the prefetch gone)
 #define H3_FENCE() __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        f32x16 (&ac)[2][2] = acc[pass];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ac[rt][c2][r] = 0.f;
-        const half8 *wl_hi = w_hi + (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;  // + (c2 * n_steps + s) * 64
-        const half8 *wl_lo = w_lo + (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;
-        auto load_b = [&](int s, FragB &f) {
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                f.h[c2] = wl_hi[((size_t)c2 * n_steps + s) * 64];
-                f.l[c2] = wl_lo[((size_t)c2 * n_steps + s) * 64];
-            }
-        };
-        // (the three terms as three sweeps over the four tiles: independent accumulators between two MFMAs on the same one)
-        auto mma = [&](const FragA &a, const FragB &b) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.l[rt], ac[rt][c2], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-                    ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
-        };
-        FragB b0, b1, b2, b3;
-        FragA a0, a1;
-        if (n_steps < 4) {  // the input layer: one k-step
-            for (int s = 0; s < n_steps; ++s) {
-                load_a(s, a0);
-                load_b(s, b0);
-                mma(a0, b0);
-            }
-            continue;
-        }
-        // (`sched_barrier`: the instruction scheduler would otherwise sink every load to just above its first use -- fewer
-        // live registers, and the prefetch gone)
-        load_b(0, b0);
-        load_b(1, b1);
-        load_b(2, b2);
-        load_a(0, a0);
-        H3_FENCE();
+    h3_zero(ac);
+    H3FragB b3;
+    H3FragA a0, a1;
+    load_a(0, a0);
+    H3_FENCE();
 #pragma unroll 1
-        for (int s = 0; s < n_steps; s += 4) {  // n_steps is a multiple of 4 (512 / 16 = 32)
-            load_b(s + 3, b3);
-            load_a(s + 1, a1);
-            H3_FENCE();
-            mma(a0, b0);
-            H3_FENCE();
-            if (s + 4 < n_steps) load_b(s + 4, b0);
-            load_a(s + 2, a0);
-            H3_FENCE();
-            mma(a1, b1);
-            H3_FENCE();
-            if (s + 5 < n_steps) load_b(s + 5, b1);
-            load_a(s + 3, a1);
-            H3_FENCE();
-            mma(a0, b2);
-            H3_FENCE();
-            if (s + 6 < n_steps) load_b(s + 6, b2);
-            if (s + 4 < n_steps) load_a(s + 4, a0);
-            H3_FENCE();
-            mma(a1, b3);
-            H3_FENCE();
-        }
+    for (int s = 0; s < n_steps - 4; s += 4) {  // n_steps is a multiple of 4 (512 / 16 = 32)
+        h3_load_b(w, n_steps, s + 3, b3);
+        load_a(s + 1, a1);
+        H3_FENCE();
+        h3_mma(ac, a0, ring.b0);
+        H3_FENCE();
+        h3_load_b(w, n_steps, s + 4, ring.b0);
+        load_a(s + 2, a0);
+        H3_FENCE();
+        h3_mma(ac, a1, ring.b1);
+        H3_FENCE();
+        h3_load_b(w, n_steps, s + 5, ring.b1);
+        load_a(s + 3, a1);
+        H3_FENCE();
+        h3_mma(ac, a0, ring.b2);
+        H3_FENCE();
+        h3_load_b(w, n_steps, s + 6, ring.b2);
+        load_a(s + 4, a0);
+        H3_FENCE();
+        h3_mma(ac, a1, b3);
+        H3_FENCE();
+    }
+    {   // the last four k-steps: the ring sets that fall free take the head of the next pass of the stream
+        constexpr int s = n_steps - 4;
+        h3_load_b(w, n_steps, s + 3, b3);
+        load_a(s + 1, a1);
+        H3_FENCE();
+        h3_mma(ac, a0, ring.b0);
+        H3_FENCE();
+        if (HAS_NEXT) h3_load_b(next, n_steps, 0, ring.b0);
+        load_a(s + 2, a0);
+        H3_FENCE();
+        h3_mma(ac, a1, ring.b1);
+        H3_FENCE();
+        if (HAS_NEXT) h3_load_b(next, n_steps, 1, ring.b1);
+        load_a(s + 3, a1);
+        H3_FENCE();
+        h3_mma(ac, a0, ring.b2);
+        H3_FENCE();
+        if (HAS_NEXT) h3_load_b(next, n_steps, 2, ring.b2);
+        H3_FENCE();
+        h3_mma(ac, a1, b3);
+        H3_FENCE();
     }
 #undef H3_FENCE
 }
 
-// bias (+ tanh), split, then this wave's [64 x 128] slice of both planes back to LDS.  Result layout (see gemm_layer_h3):
+// a 512-wide hidden layer: this wave's 128 columns of all 64 samples
+__device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Float16 *a_hi, const _Float16 *a_lo,
+                                              const unsigned short *layer, int wid, int lane) {
+    const H3Pass w0 = h3_pass(layer, H3_STEPS, wid, 0, lane), w1 = h3_pass(layer, H3_STEPS, wid, 1, lane);
+    H3Ring ring;
+    h3_prime(w0, H3_STEPS, ring);
+    gemm_pass_h3<true>(acc[0], a_hi, a_lo, w0, w1, ring, lane);
+    gemm_pass_h3<false>(acc[1], a_hi, a_lo, w1, w1, ring, lane);
+}
+
+// Linear(5 -> 512) of the step's inputs: one k-step (z rows padded to 16), both passes
+__device__ __forceinline__ void gemm_input_h3(f32x16 (&acc)[2][2][2], const _Float16 *z_hi, const _Float16 *z_lo,
+                                              const unsigned short *layer, int wid, int lane) {
+    const int aoff = (lane & 31) * H3_ZPITCH + 8 * (lane >> 5);
+    H3FragA a;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        a.h[rt] = *reinterpret_cast<const half8 *>(z_hi + rt * 32 * H3_ZPITCH + aoff);
+        a.l[rt] = *reinterpret_cast<const half8 *>(z_lo + rt * 32 * H3_ZPITCH + aoff);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const H3Pass w = h3_pass(layer, 1, wid, pass, lane);
+        H3FragB b;
+        h3_load_b(w, 1, 0, b);
+        h3_zero(acc[pass]);
+        h3_mma(acc[pass], a, b);
+    }
+}
+
+// bias (+ tanh), split, then this wave's [64 x 128] slice of both planes back to LDS.  Result layout (see gemm_pass_h3):
 // register r of tile (rt, ct) in lane l = sample 32 rt + (l & 31), feature 128 wid + 32 ct + (r & 3) + 8 (r >> 2) + 4 (l >> 5).
 // The launch spends a fifth of its time here (one wave per SIMD: nothing else issues meanwhile), so two elements at a
 // time: packed f32 arithmetic for the bias, the tanh's linear parts and the residual, and `v_cvt_pkrtz_f16_f32` for
@@ -504,6 +562,9 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
                 *reinterpret_cast<half4v *>(base[1][rt] + off) = half4v{lo[2 * q].x, lo[2 * q].y, lo[2 * q + 1].x, lo[2 * q + 1].y};
             }
         }
+        // (one column tile at a time: unfenced, the scheduler lifts the bias / weight loads of all four tiles to the top of
+        // the unrolled block and the kernel spills)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -547,8 +608,6 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     if (wid == 0) {  // the padding of the layer-0 rows stays zero
         for (int q = 0; q < H3_ZPITCH; ++q) { z_hi[lane * H3_ZPITCH + q] = (_Float16)0.f; z_lo[lane * H3_ZPITCH + q] = (_Float16)0.f; }
     }
-    const half8 *wi_hi = reinterpret_cast<const half8 *>(Q.h3_w_in), *wi_lo = wi_hi + 16 * 64;
-
     for (int t = 0; t < P.T; ++t) {
         float u0 = 0, u1 = 0, v0 = 0, v1 = 0;
         if (wid == 0) {
@@ -559,15 +618,14 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
         }
         __syncthreads();
         PH(0);
-        gemm_layer_h3(acc, z_hi, z_lo, H3_ZPITCH, wi_hi, wi_lo, 1, wid, lane);
+        gemm_input_h3(acc, z_hi, z_lo, Q.h3_w_in, wid, lane);
         PH(1);
         store_layer_h3<false>(a_hi, a_lo, acc, Q.b_in, wid, lane);
         PH(2);
         __syncthreads();
         PH(3);
         for (int l = 0; l < 2; ++l) {
-            const half8 *wh = reinterpret_cast<const half8 *>(Q.h3_w_h[l]);
-            gemm_layer_h3(acc, a_hi, a_lo, H3_PITCH, wh, wh + (size_t)16 * H3_STEPS * 64, H3_STEPS, wid, lane);
+            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane);
             PH(4);
             __syncthreads();
             PH(5);
@@ -577,8 +635,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             PH(7);
         }
         {   // the third hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's 128 of the 512 inputs
-            const half8 *wh = reinterpret_cast<const half8 *>(Q.h3_w_h[2]);
-            gemm_layer_h3(acc, a_hi, a_lo, H3_PITCH, wh, wh + (size_t)16 * H3_STEPS * 64, H3_STEPS, wid, lane);
+            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane);
             PH(4);
             float yo[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
             store_layer_h3<true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
