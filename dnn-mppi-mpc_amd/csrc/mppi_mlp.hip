@@ -330,8 +330,8 @@ __device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
 //
 // The weight stream does not stop between the two passes of a layer: the last trip of the first pass requests the first
 // three k-steps of the second into the ring sets it has just used up (an L2 round trip waited for at the top of every
-// pass before).  Across layers the ring is NOT kept: live through the epilogue it pushed the kernel into scratch spills
-// (8.3 against 6.8 ms); a layer requests its first k-steps at its top.
+// pass before).  Across layers the ring is not kept THROUGH the epilogue (that pushed the kernel into scratch spills, 8.3
+// against 6.8 ms): the next layer's first k-steps are requested right behind the epilogue (h3_prime_layer).
 struct H3FragA { half8 h[2], l[2]; };
 struct H3FragB { half8 h[2], l[2]; };
 struct H3Ring { H3FragB b0, b1, b2; };  // k-steps 0, 1, 2 of the pass about to run
@@ -449,12 +449,15 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
 #undef H3_FENCE
 }
 
-// a 512-wide hidden layer: this wave's 128 columns of all 64 samples
+// a 512-wide hidden layer: this wave's 128 columns of all 64 samples.  `ring`: the first three k-steps of the layer,
+// requested by the caller (h3_prime_layer) once the previous layer's epilogue has let go of its registers -- they fly
+// while the workgroup meets at the barrier in front of this layer.
+__device__ __forceinline__ void h3_prime_layer(const unsigned short *layer, int wid, int lane, H3Ring &ring) {
+    h3_prime(h3_pass(layer, H3_STEPS, wid, 0, lane), H3_STEPS, ring);
+}
 __device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Float16 *a_hi, const _Float16 *a_lo,
-                                              const unsigned short *layer, int wid, int lane) {
+                                              const unsigned short *layer, int wid, int lane, H3Ring &ring) {
     const H3Pass w0 = h3_pass(layer, H3_STEPS, wid, 0, lane), w1 = h3_pass(layer, H3_STEPS, wid, 1, lane);
-    H3Ring ring;
-    h3_prime(w0, H3_STEPS, ring);
     gemm_pass_h3<true>(acc[0], a_hi, a_lo, w0, w1, ring, lane);
     gemm_pass_h3<false>(acc[1], a_hi, a_lo, w1, w1, ring, lane);
 }
@@ -621,21 +624,24 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
         gemm_input_h3(acc, z_hi, z_lo, Q.h3_w_in, wid, lane);
         PH(1);
         store_layer_h3<false>(a_hi, a_lo, acc, Q.b_in, wid, lane);
+        H3Ring ring;
+        h3_prime_layer(Q.h3_w_h[0], wid, lane, ring);
         PH(2);
         __syncthreads();
         PH(3);
         for (int l = 0; l < 2; ++l) {
-            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane);
+            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane, ring);
             PH(4);
             __syncthreads();
             PH(5);
             store_layer_h3<true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
+            h3_prime_layer(Q.h3_w_h[l + 1], wid, lane, ring);
             PH(6);
             __syncthreads();
             PH(7);
         }
         {   // the third hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's 128 of the 512 inputs
-            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane);
+            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane, ring);
             PH(4);
             float yo[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
             store_layer_h3<true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
