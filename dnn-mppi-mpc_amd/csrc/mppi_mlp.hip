@@ -396,6 +396,22 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
     // (`sched_barrier`: the instruction scheduler would otherwise sink every load to just above its first use -- fewer
     // live registers, and the prefetch gone)
 #define H3_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // One k-step = 12 MFMAs (384 cycles of the matrix pipe) + the requests that keep the ring and the activation fragments
+    // ahead: 4 global loads + 4 LDS reads.  Issued as a block in front of the MFMAs they left the pipe idle while the
+    // vector-memory unit took them; the group barriers below spread them, one behind each of the first eight MFMAs.
+#define H3_SPREAD(n_vmem, n_lds)                                                                          \
+    do {                                                                                                  \
+        for (int _i = 0; _i < (n_vmem); ++_i) {                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */                             \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* one vector-memory read */               \
+        }                                                                                                 \
+        for (int _i = 0; _i < (n_lds); ++_i) {                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* one LDS read */                         \
+        }                                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12 - (n_vmem) - (n_lds), 0);                          \
+        H3_FENCE();                                                                                       \
+    } while (0)
     h3_zero(ac);
     H3FragB b3;
     H3FragA a0, a1;
@@ -405,47 +421,40 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
     for (int s = 0; s < n_steps - 4; s += 4) {  // n_steps is a multiple of 4 (512 / 16 = 32)
         h3_load_b(w, n_steps, s + 3, b3);
         load_a(s + 1, a1);
-        H3_FENCE();
         h3_mma(ac, a0, ring.b0);
-        H3_FENCE();
+        H3_SPREAD(4, 4);
         h3_load_b(w, n_steps, s + 4, ring.b0);
         load_a(s + 2, a0);
-        H3_FENCE();
         h3_mma(ac, a1, ring.b1);
-        H3_FENCE();
+        H3_SPREAD(4, 4);
         h3_load_b(w, n_steps, s + 5, ring.b1);
         load_a(s + 3, a1);
-        H3_FENCE();
         h3_mma(ac, a0, ring.b2);
-        H3_FENCE();
+        H3_SPREAD(4, 4);
         h3_load_b(w, n_steps, s + 6, ring.b2);
         load_a(s + 4, a0);
-        H3_FENCE();
         h3_mma(ac, a1, b3);
-        H3_FENCE();
+        H3_SPREAD(4, 4);
     }
     {   // the last four k-steps: the ring sets that fall free take the head of the next pass of the stream
         constexpr int s = n_steps - 4;
         h3_load_b(w, n_steps, s + 3, b3);
         load_a(s + 1, a1);
-        H3_FENCE();
         h3_mma(ac, a0, ring.b0);
-        H3_FENCE();
+        H3_SPREAD(4, 4);
         if (HAS_NEXT) h3_load_b(next, n_steps, 0, ring.b0);
         load_a(s + 2, a0);
-        H3_FENCE();
         h3_mma(ac, a1, ring.b1);
-        H3_FENCE();
+        H3_SPREAD(HAS_NEXT ? 4 : 0, 4);
         if (HAS_NEXT) h3_load_b(next, n_steps, 1, ring.b1);
         load_a(s + 3, a1);
-        H3_FENCE();
         h3_mma(ac, a0, ring.b2);
-        H3_FENCE();
+        H3_SPREAD(HAS_NEXT ? 4 : 0, 4);
         if (HAS_NEXT) h3_load_b(next, n_steps, 2, ring.b2);
-        H3_FENCE();
         h3_mma(ac, a1, b3);
-        H3_FENCE();
+        H3_SPREAD(HAS_NEXT ? 4 : 0, 0);
     }
+#undef H3_SPREAD
 #undef H3_FENCE
 }
 
