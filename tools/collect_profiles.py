@@ -62,9 +62,9 @@ def valu_entry(rows, kern):
 
 
 def copy(src_glob, dst_name):
-    hits = sorted(glob.glob(os.path.join(SRC, src_glob), recursive=True))
-    if hits:
-        shutil.copy(hits[0], os.path.join(DST, f"{R}_{dst_name}"))
+    hits = sorted(glob.glob(os.path.join(SRC, src_glob), recursive=True), key=os.path.getmtime)
+    if hits:  # (gpurun_out/ accumulates over calls: the newest)
+        shutil.copy(hits[-1], os.path.join(DST, f"{R}_{dst_name}"))
         return True
     print("missing", src_glob)
     return False
@@ -74,8 +74,10 @@ bid = build_id()
 bench = json.load(open(os.path.join(SRC, "bench.json")))
 if bench["config"]["build_id"] != bid:
     raise SystemExit(f"the profiles were taken with build {bench['config']['build_id']}, the tree is {bid}: run make_profiles.sh again")
-for f in ("bench.json", "bench_steps20.json", "bench_c4.json", "configs.jsonl"):
+for f in ("bench.json", "bench_steps20.json", "bench_c4.json", "bench_c5.json", "configs.jsonl"):
     copy(f, f)
+if os.path.exists(os.path.join(ROOT, "gpurun_out", "issue_cost.txt")):  # tools/issue_cost.hip, when it was run this round
+    shutil.copy(os.path.join(ROOT, "gpurun_out", "issue_cost.txt"), os.path.join(DST, f"{R}_issue_cost.txt"))
 copy("kt/**/*kernel_stats.csv", "kernel_stats.csv")
 copy("kt_trav/**/*kernel_stats.csv", "traversal_kernel_stats.csv")
 copy("kt_cfg/**/*kernel_stats.csv", "configs34_kernel_stats.csv")
@@ -84,8 +86,11 @@ for d in ("pmc_inst", "pmc_fetch", "pmc_write", "pmc_trav", "pmc_cfg4"):
 
 valu = {"build_id": bid,
         "_note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace (its own run each: "
-                 "tools/make_profiles.sh); valu_issue = instructions per wave x waves per SIMD x 4 clocks: a LOWER bound on "
-                 "the VALU pipe's busy time (the 64-bit multiplies of Philox and the transcendentals are quarter-rate)"}
+                 "tools/make_profiles.sh); valu_issue = instructions per wave x waves per SIMD x 4 clocks: an instruction-count "
+                 "MODEL of the VALU pipe's busy time, not a bound -- measured issue costs at four waves per SIMD "
+                 "(tools/issue_cost.hip, profiles/*_issue_cost.txt): 2.5 cycles for plain f32 / integer / logic operations on "
+                 "VGPR or literal operands, 4.3 for DPP, compares, min/max, conversions, integer multiplies (v_mad_u64_u32 "
+                 "included), packed f32 and ANY instruction with an SGPR operand, 8.3 for transcendentals"}
 for label, rows, kern in (
         ("config 2: lean rollout kernel (the hold phase and every launch of the frozen index)", reduced("pmc_inst"), "k_rollout_fused<float, 0, 1, false, 2, false>"),
         ("config 2 traversal: rollout kernel that resolves the sequential index in one launch", reduced("pmc_trav"), "k_rollout_fused<float, 0, 1, false, 2, true>"),
