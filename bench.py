@@ -449,8 +449,10 @@ def main():
                         "VALU issue (bound): the noise is drawn in-kernel (Philox) and never touches HBM, so the PMC "
                         "traffic is a tenth of the algorithmic bytes; valu_issue_frac = VALU instructions per wave x "
                         "waves per SIMD x 4 clocks / kernel_us, instruction counts from the PMC pass of this build "
-                        "(null when no such pass is committed).  Averaged over whole episodes of the driver's run, "
-                        "traversal included."}
+                        "(null when no such pass is committed) -- an instruction-count model: measured issue costs on "
+                        "gfx950 are 2.5 / 4.3 / 8.3 cycles by instruction class (tools/issue_cost.hip, DESIGN.md section 6), "
+                        "and dependent chains leave issue slots empty at four waves per SIMD.  Averaged over whole "
+                        "episodes of the driver's run, traversal included."}
         if c5:
             # the learned-dynamics rollout is bound by the matrix pipe: algorithmic flop of the network per launch (SURVEY.md
             # section 8d: 1 581 056 per trajectory-step) over the launch's duration, against the dense f16 peak.  The kernel

@@ -749,8 +749,8 @@ static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
 
 // (the RCCL carrier of a K-sharded handle, further down)
 template <typename R>
-static int step_rccl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out, mppi_stats *stats,
-                     hipStream_t s);
+static int step_rccl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
+                     mppi_stats *stats, hipStream_t s);
 template <typename R>
 static int closed_loop_rccl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s);
 
@@ -759,10 +759,7 @@ static int closed_loop_rccl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
 template <typename R>
 static int step_impl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
-    if (h->rccl_comm && h->x_nranks <= 1) {
-        if (!x0) FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_step_device_x0 on a handle with the RCCL carrier: pass the state from the host");
-        return step_rccl<R>(h, x0, eps, u_out, u0_out, stats, s);
-    }
+    if (h->rccl_comm && h->x_nranks <= 1) return step_rccl<R>(h, x0, x0_dev, eps, u_out, u0_out, stats, s);
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
     const bool by_args = x0 && h->idx_valid && h->by_args_ok;
@@ -1147,10 +1144,11 @@ static int rccl_fetch(mppi_handle *h, double *u_out, double *u0_out, mppi_stats 
 }
 
 template <typename R>
-static int step_rccl(mppi_handle *h, const double *x0, const float *eps, double *u_out, double *u0_out, mppi_stats *stats,
-                     hipStream_t s) {
+static int step_rccl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
+                     mppi_stats *stats, hipStream_t s) {
     const KParams<R> P = make_params<R>(h, eps);
-    launch_set_state<R>(P, x0, s);
+    if (x0) launch_set_state<R>(P, x0, s);
+    else launch_set_state_dev<R>(P, x0_dev, h->nx, s);  // the observed state in device memory (mppi_step_device_x0)
     if (int rc = rccl_iteration<R>(h, P, 0, nullptr, s)) return rc;
     h->dev_loop_primed = false;
     h->last_eps = eps;
