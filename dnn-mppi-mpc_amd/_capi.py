@@ -66,6 +66,10 @@ PROTOTYPES = {
     "mppi_set_mlp": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                               C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mppi_set_mlp_scaled": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mppi_set_u_prev": (C.c_int, [_H, _D]),
     "mppi_get_u_prev": (C.c_int, [_H, _D]),
     "mppi_set_waypoint_idx": (C.c_int, [_H, C.c_int32]),

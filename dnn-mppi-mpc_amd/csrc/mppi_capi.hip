@@ -378,6 +378,38 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
     return MPPI_OK;
 }
 
+extern "C" int mppi_set_mlp_scaled(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
+                                   const float *const *w_hidden, const float *const *b_hidden, const float *w_out,
+                                   const float *b_out, const double *in_mean, const double *in_scale, const double *out_mean,
+                                   const double *out_scale) {
+    if (!h || !w_in || !b_in || !w_out || !b_out) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp_scaled: null argument");
+    if ((in_mean == nullptr) != (in_scale == nullptr) || (out_mean == nullptr) != (out_scale == nullptr))
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp_scaled: a mean without its scale (or the reverse)");
+    if (hidden != 512) FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: only Linear(5,512) -> 3 x Linear(512,512) -> Linear(512,3) is built");
+    std::vector<float> wi(w_in, w_in + (size_t)hidden * 5), bi(b_in, b_in + hidden), wo(w_out, w_out + (size_t)3 * hidden),
+        bo(b_out, b_out + 3);
+    if (in_mean) {
+        for (int j = 0; j < 5; ++j)
+            if (!(in_scale[j] != 0.0)) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp_scaled: in_scale[%d] is zero", j);
+        for (int n = 0; n < hidden; ++n) {
+            double shift = 0.0;
+            for (int j = 0; j < 5; ++j) {
+                const double w = (double)w_in[(size_t)n * 5 + j] / in_scale[j];
+                wi[(size_t)n * 5 + j] = (float)w;
+                shift += w * in_mean[j];
+            }
+            bi[n] = (float)((double)b_in[n] - shift);
+        }
+    }
+    if (out_mean) {
+        for (int j = 0; j < 3; ++j) {
+            for (int n = 0; n < hidden; ++n) wo[(size_t)j * hidden + n] = (float)((double)w_out[(size_t)j * hidden + n] * out_scale[j]);
+            bo[j] = (float)((double)b_out[j] * out_scale[j] + out_mean[j]);
+        }
+    }
+    return mppi_set_mlp(h, hidden, n_hidden, wi.data(), bi.data(), w_hidden, b_hidden, wo.data(), bo.data());
+}
+
 extern "C" int mppi_set_u_prev(mppi_handle *h, const double *u) {
     if (!h || !u) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_u_prev: null argument");
     HIPCHECK(h, hipSetDevice(h->cfg.device));

@@ -87,23 +87,13 @@ class Engine:
 
         ``scalers``: optional dict with the ``StandardScaler`` statistics the model was trained with
         (train/train_diff_mlp.py:72-86): ``in_mean``/``in_scale`` (5: state then control) and ``out_mean``/``out_scale``
-        (3).  The affine maps are folded into the first and last Linear on the host, so the kernel is unchanged:
-        MLP((z - m_in) / s_in) * s_out + m_out."""
+        (3).  The affine maps are folded into the first and last Linear on the host (`mppi_set_mlp_scaled`), so the kernel
+        is unchanged: MLP((z - m_in) / s_in) * s_out + m_out."""
         def arr(k):
             v = weights[k]
             if hasattr(v, "detach"):
                 v = v.detach().cpu().numpy()
             return np.ascontiguousarray(v, dtype=np.float32)
-        if scalers is not None:
-            weights = dict(weights)
-            f64 = lambda k: np.asarray(arr(k), np.float64)
-            m_in, s_in = np.asarray(scalers["in_mean"], np.float64), np.asarray(scalers["in_scale"], np.float64)
-            m_out, s_out = np.asarray(scalers["out_mean"], np.float64), np.asarray(scalers["out_scale"], np.float64)
-            w0, b0, wo, bo = f64("input_layer.weight"), f64("input_layer.bias"), f64("out_layer.weight"), f64("out_layer.bias")
-            weights["input_layer.weight"] = w0 / s_in[None, :]
-            weights["input_layer.bias"] = b0 - (w0 / s_in[None, :]) @ m_in
-            weights["out_layer.weight"] = wo * s_out[:, None]
-            weights["out_layer.bias"] = bo * s_out + m_out
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         n_hidden = sum(1 for k in weights if k.startswith("hidden_layer.") and k.endswith(".weight"))
         w_in, b_in = arr("input_layer.weight"), arr("input_layer.bias")
@@ -114,8 +104,16 @@ class Engine:
         if w_in.shape != (hidden, 5) or w_out.shape != (3, hidden) or any(w.shape != (hidden, hidden) for w in wh):
             raise ValueError("unexpected MLP shapes (expected Linear(5,H) -> n x Linear(H,H) -> Linear(H,3))")
         PP = C.POINTER(C.c_float) * max(1, n_hidden)
-        self._ck(self.lib.mppi_set_mlp(self._h, hidden, n_hidden, fp(w_in), fp(b_in), PP(*[fp(w) for w in wh]),
-                                       PP(*[fp(b) for b in bh]), fp(w_out), fp(b_out)))
+        if scalers is None:
+            self._ck(self.lib.mppi_set_mlp(self._h, hidden, n_hidden, fp(w_in), fp(b_in), PP(*[fp(w) for w in wh]),
+                                           PP(*[fp(b) for b in bh]), fp(w_out), fp(b_out)))
+            return
+        st = {k: np.ascontiguousarray(scalers[k], dtype=np.float64) for k in ("in_mean", "in_scale", "out_mean", "out_scale")}
+        if st["in_mean"].shape != (5,) or st["in_scale"].shape != (5,) or st["out_mean"].shape != (3,) or st["out_scale"].shape != (3,):
+            raise ValueError("scalers: in_mean / in_scale have 5 entries (state, control), out_mean / out_scale 3")
+        self._ck(self.lib.mppi_set_mlp_scaled(self._h, hidden, n_hidden, fp(w_in), fp(b_in), PP(*[fp(w) for w in wh]),
+                                              PP(*[fp(b) for b in bh]), fp(w_out), fp(b_out), _dp(st["in_mean"]),
+                                              _dp(st["in_scale"]), _dp(st["out_mean"]), _dp(st["out_scale"])))
 
     def set_u_prev(self, u):
         u = np.ascontiguousarray(u, dtype=np.float64)

@@ -163,6 +163,16 @@ int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m);
  */
 int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
                  const float *const *w_hidden, const float *const *b_hidden, const float *w_out, const float *b_out);
+/*
+ * The same with the `StandardScaler` statistics the model was trained with (train/train_diff_mlp.py:72-86; values in
+ * SURVEY.md App. C): the network then sees (z - in_mean) / in_scale, z = [x, y, yaw, v, w], and its output is taken as
+ * y * out_scale + out_mean.  The two affine maps are folded into the first and the last Linear in f64 on the host
+ * (W_in / in_scale, b_in - (W_in / in_scale) in_mean; out_scale W_out, out_scale b_out + out_mean), so the kernels are
+ * the same.  in_mean / in_scale: 5 doubles, out_mean / out_scale: 3 doubles; a NULL pair means identity.
+ */
+int mppi_set_mlp_scaled(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
+                        const float *const *w_hidden, const float *const *b_hidden, const float *w_out, const float *b_out,
+                        const double *in_mean, const double *in_scale, const double *out_mean, const double *out_scale);
 /* mutable controller state: `u_prev[T,2]` and `prev_way_point_idx` / `prev_waypoints_idx`
  * (mppi_differential_drive.py:82,:85); host pointers */
 int mppi_set_u_prev(mppi_handle *h, const double *u);
