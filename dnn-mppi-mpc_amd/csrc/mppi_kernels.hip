@@ -2033,13 +2033,16 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
     const dim3 grid(fused_blocks(P.K, P.T, P.layout), MULTI ? P.n_agents : 1);
     const bool twice = (P.layout & LAYOUT_TWICE) != 0;
     const bool race = MODEL == MODEL_RACE;
-    // (the PLAIN instantiations of k_rollout_dual exist for single-agent handles only)
-    const bool plain_dual = !MULTI && P.use_philox && P.clamp_rollout && (bool)P.wrap_stage == race && (bool)P.wrap_term == race;
+    // (the PLAIN instantiations of k_rollout_dual: every single-agent form, and for batched agents the one the default
+    // layout takes -- two samples per wave, one pass)
+    const bool plain_ok = P.use_philox && P.clamp_rollout && (bool)P.wrap_stage == race && (bool)P.wrap_term == race;
+    const bool plain_dual = !MULTI && plain_ok;
     switch (P.layout & LAYOUT_KIND) {
 #define MPPI_LAUNCH_DUAL(SPW_, SEQ_, PLAIN_) \
     hipLaunchKernelGGL((k_rollout_dual<R, MODEL, SPW_, MULTI, SEQ_, PLAIN_>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials)
     case LAYOUT_DUAL:
         if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(2, 2, !MULTI); else MPPI_LAUNCH_DUAL(2, 1, !MULTI); }
+        else if (MULTI && plain_ok && !twice) MPPI_LAUNCH_DUAL(2, 1, true);
         else { if (twice) MPPI_LAUNCH_DUAL(2, 2, false); else MPPI_LAUNCH_DUAL(2, 1, false); }
         break;
     case LAYOUT_PAIR:
