@@ -159,7 +159,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (c.n_agents > 1) {
         if (c.n_agents > 4096) FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: n_agents %d > 4096", c.n_agents);
         if (c.waypoint_mode != MPPI_WAYPOINT_FROZEN || c.K_global != c.K || c.model == MPPI_MODEL_DIFFDRIVE_MLP ||
-            !fused_supported(c.T) || fused_blocks(c.K, c.T, rollout_layout(c.K, c.T, c.n_agents)) > 512)
+            !fused_supported(c.T) || fused_blocks(c.K, c.T, rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, c.precision == MPPI_PREC_F64)) > 512)
             FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
                  "several agents per handle need MPPI_WAYPOINT_FROZEN, an analytic model, T <= 128, at most 512 "
                  "rollout workgroups (K <= 8192) and no sharding");
@@ -198,7 +198,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->traj_per_block = tpb;
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
-    h->layout = rollout_layout(c.K, c.T, c.n_agents);
+    h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64);
     h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;

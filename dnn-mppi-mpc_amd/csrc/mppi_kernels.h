@@ -182,7 +182,7 @@ bool fused_supported(int T);
 // Which fused rollout kernel serves (K, T): decided ONCE per handle (it reads the MPPI_DUAL / MPPI_PAIR / MPPI_SEQ
 // overrides) and carried in KParams::layout, so that a launch costs no environment lookups.
 enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
-int rollout_layout(int K, int T, int n_agents = 1);  // n_agents: problems batched in one launch
+int rollout_layout(int K, int T, int n_agents, int model, bool f64);  // n_agents: problems batched in one launch
 int fused_blocks(int K, int T, int layout);  // workgroups = block records of one launch
 // merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
 // (`heads` / `out_heads`: the compact head arrays of the input / internal-layout output records)

@@ -610,7 +610,7 @@ constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 // waves per SIMD) so that TWO workgroups share a CU and one's state wait, barrier and record stores run under the other's
 // arithmetic -- 32 agents of K = 4096: 1.0e11 -> 1.2e11 trajectory-steps/s.  (The race car would spill to scratch.)
 template <typename R, int MODEL, int SPW, bool MULTI, int SEQ, bool PLAIN>
-__global__ __launch_bounds__(64 * DUAL_WAVES, (MULTI && sizeof(R) == 4 && MODEL == MODEL_DIFF) ? 8 : 1) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
+__global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_DIFF && SPW == 2 && (MULTI || SEQ == 1)) ? 8 : 1) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
     const int agent = MULTI ? (int)blockIdx.y : 0;  // several agents per launch (see k_rollout_fused)
     const bool use_philox = PLAIN || P.use_philox, clamp_rollout = PLAIN || P.clamp_rollout;
@@ -2011,15 +2011,18 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
-int rollout_layout(int K, int T, int n_agents) {
+int rollout_layout(int K, int T, int n_agents, int model, bool f64) {
     const int kind = dual_layout(K, T, n_agents) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
     if (kind == LAYOUT_FUSED) return kind;
     // k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per
     // CU, and at most 512 records after halving (what k_finalize merges directly).  Beyond that the longer live
     // ranges of the doubled body cost the rollout more than k_merge gains from fewer records: K = 65536 x T = 75
-    // measured 158 us per iteration against 153 us with one pass.  MPPI_SEQ=1/2 overrides for experiments.
+    // measured 158 us per iteration against 153 us with one pass.  The f32 diff-drive form with two samples per wave
+    // fits 64 VGPRs, so two of its workgroups share a CU and overlap their phases: up to 512 workgroups it stays at one
+    // pass (config 3: 21.7 -> 21.0 us per iteration).  MPPI_SEQ=1/2 overrides for experiments.
     const int blocks = fused_blocks(K, T, kind);
-    bool twice = blocks > 256 && blocks <= 1024;
+    const bool shares_cu = kind == LAYOUT_DUAL && model == MODEL_DIFF && !f64;
+    bool twice = blocks > (shares_cu ? 512 : 256) && blocks <= 1024;
     if (const char *e = getenv("MPPI_SEQ")) twice = atoi(e) == 2;
     return kind | (twice ? LAYOUT_TWICE : 0);
 }
