@@ -231,7 +231,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     // 20-candidate window, `S[k] =`, one agent, at most 256 workgroups (K <= 4096).  Anything else keeps the speculation
     // rounds alone (they also serve as this path's fallback).  MPPI_NO_HYP=1 switches it off for A/B runs.
     h->hyp = h->fused && (h->layout & LAYOUT_KIND) == LAYOUT_FUSED && c.T <= 64 && c.model == MPPI_MODEL_DIFFDRIVE &&
-             c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && c.search_window == HYP_WINDOW &&
+             c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && (c.search_window == HYP_WINDOW || c.search_window == HYP_WINDOW_CUDA) &&
              c.n_agents == 1 && h->n_part <= HYP_MAX_BLOCKS && !getenv("MPPI_NO_HYP");
     if (h->hyp) {
         const size_t nrec = (size_t)HYP_MAX_BLOCKS * HYP_R;

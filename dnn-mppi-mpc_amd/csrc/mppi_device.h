@@ -122,14 +122,17 @@ template <typename R> __device__ __forceinline__ int window_len(int window, int 
 }
 
 // ---- one-launch resolution of the sequential index (HYP_R in mppi_kernels.h) -------------------------------------
-// The HYP_CAND candidates ref[c .. c+34] as pairs (see RefPair); candidates past the end of the path are far-away
-// points that can never win, so every window [q, q+20) is truncated at the path's end like the reference's slice
+// The candidates ref[c .. c + HYP_R + W - 2] as pairs (see RefPair), W = the search window (20: the NumPy / torch files,
+// 10: `_cuda`, mppi_differential_drive_cuda.py:201); candidates past the end of the path are far-away points that can
+// never win, so every window [q, q+W) is truncated at the path's end like the reference's slice
 // (mppi_differential_drive.py:206-208).
 template <typename R>
-__device__ __forceinline__ void hyp_stage_window(RefPair<R> *sh, const R *__restrict__ ref, int c, int n_ref, int tid) {
-    if (tid < (HYP_CAND + 1) / 2) {
+__device__ __forceinline__ void hyp_stage_window(RefPair<R> *sh, const R *__restrict__ ref, int c, int n_ref, int tid,
+                                                 int window = HYP_WINDOW) {
+    const int cand = HYP_R + window - 1;
+    if (tid < (cand + 1) / 2) {
         const int j0 = c + 2 * tid, j1 = j0 + 1;
-        const bool h0 = j0 < n_ref, h1 = j1 < n_ref && 2 * tid + 1 < HYP_CAND;
+        const bool h0 = j0 < n_ref, h1 = j1 < n_ref && 2 * tid + 1 < cand;
         RefPair<R> r;
         r.x0 = h0 ? ref[4 * j0] : R(1e30);
         r.y0 = h0 ? ref[4 * j0 + 1] : R(1e30);
@@ -139,47 +142,58 @@ __device__ __forceinline__ void hyp_stage_window(RefPair<R> *sh, const R *__rest
     }
 }
 
-// This lane's call as a table: g(q) = offset of the first nearest candidate in [q, q+20), q = 0 .. HYP_R-1 (one byte
-// each), for the position (x, y).  Sliding-window first minimum in one pass over the 35 candidates: running first
-// minimum from the left over candidates 20..34 (a window's part beyond 19), from the right over 19..0 (its part up to
-// 19; `<=` hands ties to the smaller index), and per q the smaller of the two with ties to the left part.
+// This lane's call as a table: g(q) = offset of the first nearest candidate in [q, q+W), q = 0 .. HYP_R-1 (one byte
+// each), for the position (x, y).  Sliding-window first minimum in one pass over the HYP_R + W - 1 candidates, cut into
+// blocks of W: a window [q, q+W) is a suffix of its block followed by a prefix of the next one.  Running first minimum
+// from the LEFT inside every block but the first (a window's part beyond its block's end), from the RIGHT inside the
+// blocks that hold an entry offset (its part up to the block's end; `<=` hands ties to the smaller index), and per q the
+// smaller of the two with ties to the left part.  W = 20: blocks [0, 20) and [20, 35); W = 10: [0, 10), [10, 20), [20, 25).
 struct alignas(16) HypTable { unsigned w[HYP_R / 4]; };
-template <typename R> __device__ __forceinline__ HypTable hyp_table(const RefPair<R> *win, R x, R y) {
-    static_assert(HYP_R == 16 && HYP_WINDOW == 20 && HYP_CAND == 35, "hyp_table is written for 16 entries and a 20-candidate window");
+template <int W, typename R> __device__ __forceinline__ HypTable hyp_table_w(const RefPair<R> *win, R x, R y) {
+    static_assert(HYP_R == 16 && W >= 2 && W <= HYP_WINDOW, "hyp_table: 16 entries, a window of at most HYP_WINDOW candidates");
+    constexpr int CAND = HYP_R + W - 1;
     auto dist = [&](int i) {
         const RefPair<R> r = win[i >> 1];
         const R dx = x - ((i & 1) ? r.x1 : r.x0), dy = y - ((i & 1) ? r.y1 : r.y0);
         return dx * dx + dy * dy;
     };
-    R pv[HYP_R - 1];
-    int pi[HYP_R - 1];
+    // prefix first minima of candidates W .. CAND-1, restarting at every block start
+    R pv[CAND - W];
+    int pi[CAND - W];
     {
         R best = R(INFINITY);
-        int bi = HYP_WINDOW;
+        int bi = W;
 #pragma unroll
-        for (int i = HYP_WINDOW; i < HYP_CAND; ++i) {
+        for (int i = W; i < CAND; ++i) {
             const R d = dist(i);
-            if (d < best) { best = d; bi = i; }
-            pv[i - HYP_WINDOW] = best;
-            pi[i - HYP_WINDOW] = bi;
+            if (i % W == 0 || d < best) { best = d; bi = i; }
+            pv[i - W] = best;
+            pi[i - W] = bi;
         }
     }
     HypTable g;
 #pragma unroll
     for (int q = 0; q < HYP_R / 4; ++q) g.w[q] = 0u;
+    // suffix first minima from the end of the last block that holds an entry offset, restarting at every block end
+    constexpr int TOP = ((HYP_R - 1) / W + 1) * W - 1;  // last candidate of the block of entry HYP_R - 1 (all < CAND)
+    static_assert(TOP < CAND, "the block of the last entry offset lies inside the candidates");
     R sv = R(INFINITY);
-    int si = HYP_WINDOW - 1;
+    int si = TOP;
 #pragma unroll
-    for (int i = HYP_WINDOW - 1; i >= 0; --i) {
+    for (int i = TOP; i >= 0; --i) {
         const R d = dist(i);
-        if (d <= sv) { sv = d; si = i; }
+        if (i % W == W - 1 || d <= sv) { sv = d; si = i; }
         if (i < HYP_R) {
             int gi = si;
-            if (i >= 1 && pv[i - 1] < sv) gi = pi[i - 1];  // the window [i, i+19] reaches candidate 20 + (i-1)
+            // the window [i, i+W-1] reaches into the next block unless i starts a block (then it IS the block)
+            if (i % W != 0 && pv[i - 1] < sv) gi = pi[i - 1];  // prefix of the next block up to candidate i + W - 1
             g.w[i >> 2] |= (unsigned)gi << (8 * (i & 3));
         }
     }
     return g;
+}
+template <typename R> __device__ __forceinline__ HypTable hyp_table(const RefPair<R> *win, R x, R y, int window = HYP_WINDOW) {
+    return window == HYP_WINDOW_CUDA ? hyp_table_w<HYP_WINDOW_CUDA, R>(win, x, y) : hyp_table_w<HYP_WINDOW, R>(win, x, y);
 }
 
 // collision indicator of one state (mppi_differential_drive_obs.py:301-313,

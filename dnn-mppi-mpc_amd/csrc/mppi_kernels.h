@@ -29,7 +29,7 @@ __host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
 // map and one softmin record PER ENTRY INDEX; the finalize kernel composes the 256 maps (a chain of table lookups)
 // and merges the records of the realised entries.  A chain that leaves the table (HYP_OVF) falls back to the
 // speculation rounds from that workgroup on, so the result is exact either way.
-constexpr int HYP_R = 16, HYP_WINDOW = 20, HYP_CAND = HYP_R + HYP_WINDOW - 1, HYP_OVF = 255;
+constexpr int HYP_R = 16, HYP_WINDOW = 20, HYP_WINDOW_CUDA = 10, HYP_CAND = HYP_R + HYP_WINDOW - 1, HYP_OVF = 255;
 constexpr int HYP_MAX_BLOCKS = 256;  // workgroups whose maps one finalize block composes
 
 // Controller state that lives on the device (so closed loops need no host round trip).

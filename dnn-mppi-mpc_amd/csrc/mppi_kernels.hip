@@ -387,7 +387,7 @@ __device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &s
     const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
     const bool valid = k < P.K;
     const int c = sv.c, T = P.T;
-    hyp_stage_window(sh_win, P.ref, c, P.n_ref, (int)threadIdx.x);
+    hyp_stage_window(sh_win, P.ref, c, P.n_ref, (int)threadIdx.x, P.window);
     const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
     __syncthreads();
     float e0 = 0.f, e1 = 0.f;
@@ -396,7 +396,7 @@ __device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &s
     if (valid) {
         Rollout<R, MODEL_DIFF, OBS, PLAIN> r(P, sv, k, lane, nullptr, obs, 0);
         const auto sp = r.dynamics(0, e0, e1);
-        const HypTable g = hyp_table(sh_win, sp.x, sp.y);
+        const HypTable g = hyp_table(sh_win, sp.x, sp.y, P.window);
         *reinterpret_cast<HypTable *>(&sh_g[wid][lane][0]) = g;
         wave_lds_sync();
         // compose the T stage calls: lane group s chains calls [s Ts, (s+1) Ts) from every entry offset, then the

@@ -232,7 +232,10 @@ def test_sequential_index_exact_on_curved_paths(monkeypatch, seed):
     u_in = np.column_stack([rng.uniform(0.3, 1.0, T) * kw["max_speed"], rng.normal(0, 0.3, T)])
     eps = philox.sample_epsilon(kw["sigma"], 31 + seed, 0, K, T)
     o = mppi_oracle.DiffDriveOracle(**kw)
-    c = pkg.MPPIAlgorithms(**kw, precision="f64")
+    variant = "cuda" if seed % 4 == 3 else "numpy"  # (a quarter of the sweep with the 10-candidate window of `_cuda`)
+    if variant == "cuda":
+        o.SEARCH_IDX_LEN, o.WRAP_YAW_TERMINAL = 10, True
+    c = pkg.MPPIAlgorithms(**kw, precision="f64", variant=variant)
     o.u_prev[:] = u_in
     c.u_prev[:] = u_in
     o.prev_way_point_idx = c.prev_way_point_idx = max(0, i0 - int(rng.integers(0, 4)))
@@ -323,12 +326,15 @@ def test_exchange_api_errors():
     assert e.lib.mppi_comm_handle_bytes() == 64
 
 
+@pytest.mark.parametrize("variant", ["numpy", "cuda"])
 @pytest.mark.parametrize("precision", ["f64", "f32"])
-def test_one_launch_index_resolution_and_its_fallback(precision):
+def test_one_launch_index_resolution_and_its_fallback(precision, variant):
     """The sequential index resolved in one launch (per-call maps on 16 entry indices, fused_hyp) and its fallback: on a
     densely sampled path a fast robot carries the index further than the table reaches within one iteration, so the
     chain leaves it in some workgroup and the speculation rounds take over from there (rounds > 1); on a coarse path
-    the table suffices (rounds == 1).  Either way index, costs and controls equal the oracle's."""
+    the table suffices (rounds == 1).  Either way index, costs and controls equal the oracle's.  `variant="cuda"`: the
+    10-candidate window (and terminal yaw wrap) of mppi_differential_drive_cuda.py:201,:239 -- three blocks of
+    candidates in the sliding-window minimum instead of two."""
     import dnn_mppi_mpc_amd as pkg
     seen = set()
     for n_ref, speed in ((400, 4.0), (60, 1.0)):
@@ -339,7 +345,9 @@ def test_one_launch_index_resolution_and_its_fallback(precision):
         u_in = np.column_stack([np.full(T, speed), rng.normal(0, 0.05, T)])
         eps = philox.sample_epsilon(kw["sigma"], 5, 0, K, T)
         o = mppi_oracle.DiffDriveOracle(**kw)
-        c = pkg.MPPIAlgorithms(**kw, precision=precision)
+        if variant == "cuda":
+            o.SEARCH_IDX_LEN, o.WRAP_YAW_TERMINAL = 10, True
+        c = pkg.MPPIAlgorithms(**kw, precision=precision, variant=variant)
         o.u_prev[:] = u_in
         c.u_prev[:] = u_in
         c._calc_epsilon = lambda *a, **k: eps
