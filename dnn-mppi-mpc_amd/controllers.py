@@ -455,8 +455,6 @@ class MPPIAlgorithms(_ControllerBase):
             waypoint_mode = "sequential" if process_group is None else "frozen"
         if learned_dynamics is not None and hasattr(learned_dynamics, "state_dict"):
             learned_dynamics = learned_dynamics.state_dict()  # a torch module (train/train_diff_mlp.py:13-36)
-        if learned_dynamics is not None:  # BASELINE config 5: no visualisation rollouts for this model
-            self.visualze_sampled_trajs_requested = self.visualze_sampled_trajs
         cfg = dict(
             model=capi.MODEL_DIFFDRIVE if learned_dynamics is None else capi.MODEL_DIFFDRIVE_MLP,
             K=self.K, T=self.T, delta_t=self.delta_t,
@@ -490,7 +488,7 @@ class MPPIAlgorithms(_ControllerBase):
         if st.path_end:
             print("[ERROR] Reached the end of the reference path.")  # :98
         # both viz rollouts hang off `visualze_sampled_trajs` in the reference (:145,:154)
-        want = self.visualze_sampled_trajs and not self._learned
+        want = self.visualze_sampled_trajs  # (learned dynamics too: the same loop with the transition swapped)
         opt, smp = self._viz(want, want)
         return self._u_host[0], self._u_host, opt, smp
 

@@ -1028,12 +1028,14 @@ extern "C" int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *samp
     if (rc) return rc;
     SINGLE_AGENT_ONLY(h, "mppi_rollout_viz");
     if (h->iter < 1) FAIL(h, MPPI_ERR_STATE, "mppi_rollout_viz before the first mppi_step");
-    if (h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP)
-        FAIL(h, MPPI_ERR_UNSUPPORTED, "visualisation rollouts are not built for the learned-dynamics model");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     const float *eps = h->last_philox ? nullptr : h->last_eps;
     const int T = h->cfg.T;
-    if (h->f64) {
+    if (h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP) {  // (fp32 only, checked at create)
+        KParams<float> P = make_params<float>(h, eps);
+        const float *hist = (const float *)h->d_uhist;
+        launch_viz_mlp(P, h->mlp, hist, hist + 2 * T, h->iter - 1, optimal_traj, sampled_traj, (hipStream_t)stream);
+    } else if (h->f64) {
         KParams<double> P = make_params<double>(h, eps);
         const double *hist = (const double *)h->d_uhist;
         launch_viz<double>(P, hist, hist + 2 * T, h->iter - 1, optimal_traj, sampled_traj, (hipStream_t)stream);

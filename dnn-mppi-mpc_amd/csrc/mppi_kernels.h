@@ -216,6 +216,10 @@ void launch_viz(const KParams<R> &P, const R *u_before, const R *u_after_pre_shi
 int reduce_blocks(int K, int traj_per_block);
 // config 5: rollout through the residual MLP on MFMA, one record per 64-sample tile
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s);
+// the visualisation rollouts (mppi_differential_drive.py:144-159) with the learned model: opt [T][3], smp [K][T][3] (either
+// may be null); u_before / u_upd: the nominal controls before the update and the updated, unshifted ones
+void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
+                    float *opt, float *smp, hipStream_t s);
 int mlp_blocks(int K);
 void pack_linear(const float *w, int n_in, float *packed);  // host: [512][n_in] -> fragment order
 void pack_linear_h3(const float *w, int n_in, unsigned short *packed);  // host: -> two f16 planes in fragment order

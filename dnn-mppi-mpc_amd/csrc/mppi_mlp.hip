@@ -137,15 +137,54 @@ __device__ __forceinline__ void mlp_controls(const KParams<float> &P, unsigned i
     }
 }
 
-// Euler step of f + MLP (bullet_differential_drive_dnn.py:79-92), this call's waypoint index and costs
-__device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLanes<float> &obs, int c, int t, float r0, float r1,
-                                            float r2, float u0, float u1, float v0, float v1, MlpLane &L) {
-    const float *__restrict__ ref = P.ref;
+// Euler step of f + MLP (bullet_differential_drive_dnn.py:79-92)
+__device__ __forceinline__ void mlp_euler(const KParams<float> &P, float r0, float r1, float r2, float v0, float v1, MlpLane &L) {
     float sn, cs;
     mf::sincos_(L.yaw, sn, cs);
     L.x = L.x + P.dt * (v0 * cs + r0);
     L.y = L.y + P.dt * (v0 * sn + r1);
     L.yaw = L.yaw + P.dt * (v1 + r2);
+}
+
+// The visualisation rollouts with this model (mppi_differential_drive.py:144-159; the reference never wires the learned
+// model into MPPI, so this is the analytic controllers' loop with the transition swapped, like the rollout itself): step t
+// is driven by control (t-1) mod T -- the reference's `[t-1]` indexing --, always clamped (:148,:158); rows 0..K-1 the
+// samples' perturbed controls of the iteration just finished (its noise regenerated), one extra row the updated nominal
+// sequence.  `VIZ` instantiation of the rollout kernel: same network code, no costs, the states stored instead.
+struct MlpViz {
+    const float *u_before, *u_upd;  // [T][2]: nominal controls before the update / updated, unshifted
+    float *opt, *smp;               // [T][3], [K][T][3] (either may be null)
+    unsigned iter;                  // the iteration whose noise the samples used
+    int block0;                     // first workgroup of the launch (the samples' workgroups are left out without `smp`)
+};
+__device__ __forceinline__ void mlp_controls_viz(const KParams<float> &P, const MlpViz &V, int k, int t, bool sample_row,
+                                                 bool opt_row, bool exploit, float &v0, float &v1) {
+    const int tc = (t + P.T - 1) % P.T;
+    v0 = 0.f;
+    v1 = 0.f;
+    if (opt_row) {
+        v0 = V.u_upd[2 * tc];
+        v1 = V.u_upd[2 * tc + 1];
+    } else if (sample_row) {
+        float e0, e1;
+        if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, V.iter, (unsigned)(k + P.k_offset), tc, P.chol, e0, e1, (unsigned)P.noise_stream);
+        else {
+            const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + tc) * 2);
+            e0 = e.x;
+            e1 = e.y;
+        }
+        v0 = exploit ? V.u_before[2 * tc] + e0 : e0;
+        v1 = exploit ? V.u_before[2 * tc + 1] + e1 : e1;
+    }
+    v0 = mf::clamp(v0, P.umax0);
+    v1 = mf::clamp(v1, P.umax1);
+}
+
+// this call's waypoint index and costs behind the Euler step
+__device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLanes<float> &obs, int c, int t, float r0, float r1,
+                                            float r2, float u0, float u1, float v0, float v1, MlpLane &L) {
+    const float *__restrict__ ref = P.ref;
+    mlp_euler(P, r0, r1, r2, v0, v1, L);
     // waypoint index of this call: per-lane, so the sequential index threads through the sample's own
     // calls in order by construction (mppi_differential_drive.py:228)
     auto nearest = [&](int from) {
@@ -593,8 +632,9 @@ __device__ unsigned long long g_mlp_phase[16];
     do {      \
     } while (0)
 #endif
+template <bool VIZ>
 __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KParams<float> P, const MlpParams Q,
-                                                                       float *__restrict__ partials) {
+                                                                       float *__restrict__ partials, const MlpViz V) {
 #ifdef MPPI_STAMPS
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
@@ -606,12 +646,14 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     float *ypart = reinterpret_cast<float *>(z_lo + MLP_M * H3_ZPITCH);  // [4][64][4]
     float *ref_lds = ypart + MLP_WAVES * MLP_M * 4;                     // [n_ref][4] when the path fits
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * MLP_M, k = k0 + lane;
+    const int k0 = ((int)blockIdx.x + (VIZ ? V.block0 : 0)) * MLP_M, k = k0 + lane;
     const KParams<float> PL = mlp_stage_path(P, ref_lds);
     const DevState sv = load_state(P, P.st);
     const ObsLanes<float> obs = load_obstacles(P, lane);
-    if (k0 + MLP_M <= sv.k_start) return;
+    if (!VIZ && k0 + MLP_M <= sv.k_start) return;
     const bool valid = k < P.K, live = valid && k >= sv.k_start;
+    // VIZ: the workgroup behind the samples' carries the nominal sequence in its lane 0
+    const bool opt_row = VIZ && k0 >= P.K && lane == 0 && V.opt != nullptr, smp_row = VIZ && valid && V.smp != nullptr;
     const int c = sv.c;
     const unsigned iter = (unsigned)sv.iter;
     MlpLane L{(float)sv.x0[0], (float)sv.x0[1], (float)sv.x0[2], 0.f, c};
@@ -623,7 +665,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     for (int t = 0; t < P.T; ++t) {
         float u0 = 0, u1 = 0, v0 = 0, v1 = 0;
         if (wid == 0) {
-            mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
+            if (VIZ) mlp_controls_viz(P, V, k, t, smp_row, opt_row, exploit, v0, v1);
+            else mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
             const float z[5] = {L.x, L.y, L.yaw, v0, v1};
 #pragma unroll
             for (int q = 0; q < 5; ++q) split_h3(z[q], z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
@@ -674,11 +717,17 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
                 r1 += o.v[1];
                 r2 += o.v[2];
             }
-            mlp_advance(PL, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
+            if (VIZ) {
+                mlp_euler(P, r0, r1, r2, v0, v1, L);
+                float *dst = opt_row ? V.opt + (size_t)t * 3 : smp_row ? V.smp + ((size_t)k * P.T + t) * 3 : nullptr;
+                if (dst) { dst[0] = L.x; dst[1] = L.y; dst[2] = L.yaw; }
+            } else {
+                mlp_advance(PL, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
+            }
         }
         PH(9);
     }
-    if (wid == 0) mlp_record(P, partials, iter, k, c, valid, live, L, lane);
+    if (!VIZ && wid == 0) mlp_record(P, partials, iter, k, c, valid, live, L, lane);
 #ifdef MPPI_STAMPS
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && wid == 1)
         for (int i = 0; i < 10; ++i) g_mlp_phase[i] = ph[i];
@@ -693,7 +742,7 @@ extern "C" int mppi_debug_mlp_phases(unsigned long long *out) {
 
 int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
 
-void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
+static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *partials, const MlpViz *viz, hipStream_t s) {
     const size_t ref_lds = sizeof(float) * 4 * MLP_REF_LDS_MAX;  // the path (mlp_stage_path)
     const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4) + ref_lds;
     const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * MLP_WAVES * MLP_M * 4 + ref_lds;
@@ -704,14 +753,32 @@ void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *parti
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem_f32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem_h3);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem_h3);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    if (Q.use_h3)
-        hipLaunchKernelGGL(k_rollout_mlp_h3, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials);
+    if (viz)  // the samples' workgroups (when their trajectories are wanted) and one for the nominal sequence (likewise)
+        hipLaunchKernelGGL(k_rollout_mlp_h3<true>, dim3((viz->smp ? mlp_blocks(P.K) : 0) + (viz->opt ? 1 : 0)),
+                           dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials, *viz);
+    else if (Q.use_h3)
+        hipLaunchKernelGGL(k_rollout_mlp_h3<false>, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials,
+                           MlpViz{nullptr, nullptr, nullptr, nullptr, 0u, 0});
     else
         hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
+}
+
+void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
+    launch_mlp_any(P, Q, partials, nullptr, s);
+}
+
+// (the f16-split kernel serves the visualisation whichever rollout kernel MPPI_MLP_F32 selects: both weight sets are packed)
+void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
+                    float *opt, float *smp, hipStream_t s) {
+    if (!opt && !smp) return;
+    const MlpViz v{u_before, u_upd, opt, smp, (unsigned)iter, smp ? 0 : mlp_blocks(P.K)};
+    launch_mlp_any(P, Q, nullptr, &v, s);
 }
 
 // Host-side packing of a torch Linear weight [n_out = 512][n_in] into fragment order:

@@ -264,6 +264,8 @@ int mppi_set_iteration(mppi_handle *h, int64_t iteration);
  * The visualisation rollouts of the last iteration (mppi_differential_drive.py:144-159):
  * optimal_traj[T,nx] from the updated u and sampled_traj[K,T,nx] from the clamped v, both
  * with the reference's `[t-1]` control indexing.  Device float buffers, either nullable.
+ * MPPI_MODEL_DIFFDRIVE_MLP: the same loop with the learned transition (the rollout kernel's network code, states stored
+ * instead of costs).
  */
 int mppi_rollout_viz(mppi_handle *h, float *optimal_traj, float *sampled_traj, void *stream);
 

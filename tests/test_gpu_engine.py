@@ -490,6 +490,34 @@ def test_learned_dynamics_mfma_rollout_against_oracle(waypoint_mode):
         assert c.prev_way_point_idx == ref["idx_after"]
 
 
+def test_learned_dynamics_visualisation_rollouts():
+    """`visualze_sampled_trajs=True` with the learned model: the reference's visualisation loop (:144-159 -- step t driven
+    by control t-1, always clamped, u clamped in place) with the transition swapped, against the oracle's
+    `viz_trajectories` (f64).  States after T recurrent steps through the network: 1e-3."""
+    import dnn_mppi_mpc_amd as pkg
+    K, T = 200, 20
+    kw, w, eps = _mlp_case(K, T, 2, visualize_optimal_traj=True, visualze_sampled_trajs=True, max_speed=1.5)
+    x0 = np.array([0.2, 0.1, -0.2])
+    tt = np.arange(T)
+    u_in = np.stack([1.3 + 0.4 * np.sin(0.3 * tt), 0.1 * np.cos(0.2 * tt)], axis=1)  # (clamping active in places)
+    o = mppi_oracle.DiffDriveMlpOracle(**kw, mlp_weights=w)
+    o.u_prev[:] = u_in
+    ref = o.iteration(x0, eps.astype(np.float64))
+    opt_ref, smp_ref = o.viz_trajectories(x0, ref["u_pre_shift"], ref["v"])
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w)
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: eps
+    u0, u, opt, smp = c._calc_input_control(x0)
+    assert rmse(u, ref["u_returned"]) <= 1e-4
+    assert opt.shape == (T, 3) and smp.shape == (K, T, 3)
+    np.testing.assert_allclose(opt, opt_ref, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(smp, smp_ref, rtol=1e-3, atol=1e-3)
+    # only the nominal sequence's trajectory: the samples' workgroups are left out of the launch
+    opt_only, none = c._engine.rollout_viz(True, False)
+    assert none is None
+    np.testing.assert_allclose(opt_only.cpu().numpy(), opt_ref, rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("obstacles", [0, 5])
 def test_learned_dynamics_zero_residual_equals_analytic_kernel(obstacles):
     """out_layer = 0: the MFMA rollout must reproduce the analytic scan kernel (same costs, same update), with
