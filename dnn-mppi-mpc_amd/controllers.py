@@ -493,9 +493,8 @@ class MPPIAlgorithms(_ControllerBase):
         return self._u_host[0], self._u_host, opt, smp
 
     def _state_transition(self, x_t, v_t):
-        """`_state_transition` (:182-198): Euler step of the unicycle (of the residual model when one is loaded: not built)."""
-        if self._learned:
-            raise NotImplementedError("the batched transition of the learned model is not exposed")
+        """`_state_transition` (:182-198): Euler step of the unicycle -- of the residual model x + dt (f + MLP([x, v])) when
+        one is loaded (test/bullet_differential_drive_dnn.py:79-92)."""
         return self._transition(x_t, v_t)
 
     def _compute_cost(self, x_t):

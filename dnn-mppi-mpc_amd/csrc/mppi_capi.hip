@@ -1426,6 +1426,11 @@ struct DevBuf {  // scratch device buffer released at scope exit
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
+static void eval_transition_mlp(mppi_handle *h, const KParams<float> &P, const void *x, const void *v, int n, void *out) {
+    launch_eval_mlp(P, h->mlp, (const float *)x, (const float *)v, n, (float *)out, nullptr);
+}
+static void eval_transition_mlp(mppi_handle *, const KParams<double> &, const void *, const void *, int, void *) {}  // rejected at create
+
 template <typename R>
 static int eval_impl(mppi_handle *h, int what, const double *x, const double *v, int n, int32_t *prev_idx, int update,
                      double *out, int32_t *idx_out) {
@@ -1452,7 +1457,10 @@ static int eval_impl(mppi_handle *h, int what, const double *x, const double *v,
     }
     if (what >= 0) {
         HIPCHECK(h, dout.alloc(sizeof(R) * (size_t)n * n_out));
-        launch_eval<R>(P, what, (const R *)dx.p, (const R *)dv.p, (const int *)di.p, n, (R *)dout.p, nullptr);
+        if (what == EVAL_TRANSITION && h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP)  // x + dt (f + MLP([x, v])), fp32 handles only
+            eval_transition_mlp(h, P, dx.p, dv.p, n, dout.p);
+        else
+            launch_eval<R>(P, what, (const R *)dx.p, (const R *)dv.p, (const int *)di.p, n, (R *)dout.p, nullptr);
     }
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipDeviceSynchronize());

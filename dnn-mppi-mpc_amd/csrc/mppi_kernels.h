@@ -218,6 +218,8 @@ int reduce_blocks(int K, int traj_per_block);
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s);
 // the visualisation rollouts (mppi_differential_drive.py:144-159) with the learned model: opt [T][3], smp [K][T][3] (either
 // may be null); u_before / u_upd: the nominal controls before the update and the updated, unshifted ones
+// `_state_transition` with the learned model for n (state, control) rows: x [n][3], v [n][2] -> out [n][3]
+void launch_eval_mlp(const KParams<float> &P, const MlpParams &Q, const float *x, const float *v, int n, float *out, hipStream_t s);
 void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
                     float *opt, float *smp, hipStream_t s);
 int mlp_blocks(int K);

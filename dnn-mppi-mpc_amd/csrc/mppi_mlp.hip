@@ -156,6 +156,11 @@ struct MlpViz {
     float *opt, *smp;               // [T][3], [K][T][3] (either may be null)
     unsigned iter;                  // the iteration whose noise the samples used
     int block0;                     // first workgroup of the launch (the samples' workgroups are left out without `smp`)
+    // `_state_transition` of the learned model, batched (mppi_eval_state_transition): row k takes ONE Euler step from
+    // ex[k] under the control ev[k] as it is given
+    const float *ex, *ev;           // [en][3], [en][2]
+    float *eout;                    // [en][3]
+    int en;
 };
 __device__ __forceinline__ void mlp_controls_viz(const KParams<float> &P, const MlpViz &V, int k, int t, bool sample_row,
                                                  bool opt_row, bool exploit, float &v0, float &v1) {
@@ -653,19 +658,25 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     if (!VIZ && k0 + MLP_M <= sv.k_start) return;
     const bool valid = k < P.K, live = valid && k >= sv.k_start;
     // VIZ: the workgroup behind the samples' carries the nominal sequence in its lane 0
-    const bool opt_row = VIZ && k0 >= P.K && lane == 0 && V.opt != nullptr, smp_row = VIZ && valid && V.smp != nullptr;
+    const bool eval = VIZ && V.ex != nullptr, eval_row = eval && k < V.en;
+    const bool opt_row = VIZ && !eval && k0 >= P.K && lane == 0 && V.opt != nullptr;
+    const bool smp_row = VIZ && !eval && valid && V.smp != nullptr;
     const int c = sv.c;
     const unsigned iter = (unsigned)sv.iter;
     MlpLane L{(float)sv.x0[0], (float)sv.x0[1], (float)sv.x0[2], 0.f, c};
+    if (eval_row) { L.x = V.ex[3 * k]; L.y = V.ex[3 * k + 1]; L.yaw = V.ex[3 * k + 2]; }
+    const int n_steps = eval ? 1 : P.T;
     const bool exploit = (k + P.k_offset) < P.n_exploit;
     f32x16 acc[2][2][2];
     if (wid == 0) {  // the padding of the layer-0 rows stays zero
         for (int q = 0; q < H3_ZPITCH; ++q) { z_hi[lane * H3_ZPITCH + q] = (_Float16)0.f; z_lo[lane * H3_ZPITCH + q] = (_Float16)0.f; }
     }
-    for (int t = 0; t < P.T; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         float u0 = 0, u1 = 0, v0 = 0, v1 = 0;
         if (wid == 0) {
-            if (VIZ) mlp_controls_viz(P, V, k, t, smp_row, opt_row, exploit, v0, v1);
+            if (eval) {
+                if (eval_row) { v0 = V.ev[2 * k]; v1 = V.ev[2 * k + 1]; }
+            } else if (VIZ) mlp_controls_viz(P, V, k, t, smp_row, opt_row, exploit, v0, v1);
             else mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
             const float z[5] = {L.x, L.y, L.yaw, v0, v1};
 #pragma unroll
@@ -719,7 +730,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             }
             if (VIZ) {
                 mlp_euler(P, r0, r1, r2, v0, v1, L);
-                float *dst = opt_row ? V.opt + (size_t)t * 3 : smp_row ? V.smp + ((size_t)k * P.T + t) * 3 : nullptr;
+                float *dst = eval_row ? V.eout + (size_t)k * 3
+                             : opt_row ? V.opt + (size_t)t * 3 : smp_row ? V.smp + ((size_t)k * P.T + t) * 3 : nullptr;
                 if (dst) { dst[0] = L.x; dst[1] = L.y; dst[2] = L.yaw; }
             } else {
                 mlp_advance(PL, obs, c, t, r0, r1, r2, u0, u1, v0, v1, L);
@@ -760,11 +772,12 @@ static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *pa
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     if (viz)  // the samples' workgroups (when their trajectories are wanted) and one for the nominal sequence (likewise)
-        hipLaunchKernelGGL(k_rollout_mlp_h3<true>, dim3((viz->smp ? mlp_blocks(P.K) : 0) + (viz->opt ? 1 : 0)),
+        hipLaunchKernelGGL(k_rollout_mlp_h3<true>,
+                           dim3(viz->ex ? mlp_blocks(viz->en) : (viz->smp ? mlp_blocks(P.K) : 0) + (viz->opt ? 1 : 0)),
                            dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials, *viz);
     else if (Q.use_h3)
         hipLaunchKernelGGL(k_rollout_mlp_h3<false>, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials,
-                           MlpViz{nullptr, nullptr, nullptr, nullptr, 0u, 0});
+                           MlpViz{nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr, nullptr, 0});
     else
         hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
 }
@@ -777,8 +790,13 @@ void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *parti
 void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
                     float *opt, float *smp, hipStream_t s) {
     if (!opt && !smp) return;
-    const MlpViz v{u_before, u_upd, opt, smp, (unsigned)iter, smp ? 0 : mlp_blocks(P.K)};
+    const MlpViz v{u_before, u_upd, opt, smp, (unsigned)iter, smp ? 0 : mlp_blocks(P.K), nullptr, nullptr, nullptr, 0};
     launch_mlp_any(P, Q, nullptr, &v, s);
+}
+
+void launch_eval_mlp(const KParams<float> &P, const MlpParams &Q, const float *x, const float *v, int n, float *out, hipStream_t s) {
+    const MlpViz e{nullptr, nullptr, nullptr, nullptr, 0u, 0, x, v, out, n};
+    launch_mlp_any(P, Q, nullptr, &e, s);
 }
 
 // Host-side packing of a torch Linear weight [n_out = 512][n_in] into fragment order:

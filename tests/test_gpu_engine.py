@@ -518,6 +518,23 @@ def test_learned_dynamics_visualisation_rollouts():
     np.testing.assert_allclose(opt_only.cpu().numpy(), opt_ref, rtol=1e-3, atol=1e-3)
 
 
+def test_learned_dynamics_state_transition_stage_method():
+    """`_state_transition(x_t, v_t)` with a learned model loaded: x + dt (f(x, v) + MLP([x, v]))
+    (test/bullet_differential_drive_dnn.py:79-92) for a single call and for a ragged batch, against the f64 forward."""
+    import dnn_mppi_mpc_amd as pkg
+    kw, w, _ = _mlp_case(64, 20, 3)
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w)
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 64, 131):
+        x = rng.normal(0, 1.0, (n, 3))
+        v = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n)])
+        r = mppi_oracle.mlp_forward(w, np.concatenate([x, v], axis=1))
+        f = np.stack([v[:, 0] * np.cos(x[:, 2]), v[:, 0] * np.sin(x[:, 2]), v[:, 1]], axis=1)
+        want = x + kw["delta_t"] * (f + r)
+        np.testing.assert_allclose(c._state_transition(x, v), want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c._state_transition(x[0], v[0]), want[0], rtol=1e-5, atol=1e-5)  # the reference's call shape
+
+
 @pytest.mark.parametrize("obstacles", [0, 5])
 def test_learned_dynamics_zero_residual_equals_analytic_kernel(obstacles):
     """out_layer = 0: the MFMA rollout must reproduce the analytic scan kernel (same costs, same update), with
