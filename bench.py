@@ -386,6 +386,15 @@ def main():
         barrier()
         ctrl, eng, dt, idx_timed, k1, k2, n_kernel_iters, kms, phases = measure()
 
+    # what the HOST needs to enqueue one iteration's launches when nothing holds it back (a short call into an idle queue):
+    # the loop is GPU-paced only while this stays below the iteration time
+    host_enq = None
+    if not sharded:
+        barrier()
+        ht0 = eng.host_timing()
+        eng.run_closed_loop(200, stream=stream)
+        ht1 = eng.host_timing()
+        host_enq = (ht1["enqueue_s"] - ht0["enqueue_s"]) / 200
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
     if not sharded and not c4 and not c5:
@@ -514,6 +523,7 @@ def main():
                                    {"traverse (first %d iterations of an episode)" % traverse: 1e6 * phases["traverse"],
                                     "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
+               "host_enqueue_us_per_iteration": None if host_enq is None else 1e6 * host_enq,
                "roofline": roof}
         if world == 1 and not c4 and not c5 and not args.no_batched:
             out["batched_agents"] = batched_agents()

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include <string>
 #include <vector>
 
@@ -16,6 +18,12 @@
 using namespace mppi;
 
 static thread_local std::string g_create_error;
+
+static double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 struct RcclUniqueId { char internal[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed by value to ncclCommInitRank
 
@@ -71,6 +79,7 @@ struct mppi_handle {
     int rccl_rank = 0, rccl_nranks = 0;
     double *d_rccl_part = nullptr, *d_rccl_gath = nullptr;
     long long n_rollout_launches = 0, n_finalize_launches = 0;  // mppi_get_counters
+    double t_enqueue_s = 0.0, t_loop_s = 0.0;  // mppi_get_host_timing: closed-loop calls, enqueueing / whole call
     std::string err;
 };
 
@@ -1347,6 +1356,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     h->dev_loop_primed = false;
     long long done = h->iter;
     int guard = 0;
+    const double t_call = now_s();
     // While the HYPK kernels are in use the host looks in on the waypoint index after 32, 64, 128 ... slots: at the end
     // of the path (the reference driver's run reaches it after some 23 of its 1000 iterations) the lean kernels take over
     long long batch = P.hyp ? 32 : (1LL << 62);
@@ -1356,6 +1366,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         // the host polls (as mppi_step does): no copy launch and no stream synchronisation at the end of the call
         // (14 -> 7 us of fixed cost per call).  Several agents per handle: one result per agent, copied as before.
         const bool poll = h->poll && h->B == 1;
+        const double t_enq = now_s();
         for (long long i = 0; i < todo; ++i) {
             if (poll && i == todo - 1) {
                 FinalizeParams Fl = F;
@@ -1367,6 +1378,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
             }
         }
         HIPCHECK(h, hipGetLastError());
+        h->t_enqueue_s += now_s() - t_enq;
         if (poll) {
             if (int rc = wait_result(h, h->seq, s)) return rc;
         } else {
@@ -1391,6 +1403,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         }
         if (++guard > h->cfg.K + 64) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
     }
+    h->t_loop_s += now_s() - t_call;
     h->last_eps = nullptr;
     h->last_philox = true;
     h->idx = h->h_res->idx_after;
@@ -1545,6 +1558,13 @@ extern "C" int mppi_get_counters(mppi_handle *h, int64_t *out3) {
     out3[0] = h->iter;
     out3[1] = h->n_rollout_launches;
     out3[2] = h->n_finalize_launches;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_get_host_timing(const mppi_handle *h, double *out2) {
+    if (!h || !out2) return MPPI_ERR_BAD_ARG;
+    out2[0] = h->t_enqueue_s;
+    out2[1] = h->t_loop_s;
     return MPPI_OK;
 }
 

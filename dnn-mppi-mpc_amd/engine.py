@@ -355,6 +355,12 @@ class Engine:
             self._ck(self.lib.mppi_get_rollout_layout(self._h, C.byref(layout)))
         return {"iterations": out[0], "rollout_launches": out[1], "finalize_launches": out[2], "rollout_layout": layout.value}
 
+    def host_timing(self):
+        """Seconds this handle's closed-loop calls spent enqueueing launches / inside the calls (cumulative)."""
+        out = (C.c_double * 2)()
+        self._ck(self.lib.mppi_get_host_timing(self._h, out))
+        return {"enqueue_s": out[0], "loop_s": out[1]}
+
     def last_kernel_ms(self):
         out = (C.c_float * 4)()
         self._ck(self.lib.mppi_last_kernel_ms(self._h, out))

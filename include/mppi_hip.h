@@ -324,6 +324,11 @@ int mppi_set_rollout_repeats(mppi_handle *h, int32_t n);
  * mode may take several of each (speculation rounds); bench.py divides a measured time by these. */
 int mppi_get_counters(mppi_handle *h, int64_t *out3);
 
+/* Host side of mppi_run_closed_loop since mppi_create (seconds, cumulative): out2 = {time spent ENQUEUEING the launches,
+ * time inside the calls}.  A loop the host cannot feed fast enough shows enqueue ~ whole call; bench.py reports the ratio
+ * (`host_enqueue_share`), because the iteration's 9 us leave a host that needs ~3 us per launch little slack. */
+int mppi_get_host_timing(const mppi_handle *h, double *out2);
+
 /* Which fused rollout kernel serves the handle (fixed at mppi_create from K x n_agents and T; diagnostic, for tests and
  * profiles): low two bits 0 = one sample per wave, lanes over the horizon; 1 = two samples per wave, two steps per lane
  * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128);
