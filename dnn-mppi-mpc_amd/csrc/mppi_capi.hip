@@ -1075,11 +1075,8 @@ struct RcclApi {
     const char *(*GetErrorString)(int) = nullptr;
     std::string why;
 };
-RcclApi &rccl_api() {
-    static RcclApi a;
-    static bool tried = false;
-    if (tried) return a;
-    tried = true;
+RcclApi rccl_load() {
+    RcclApi a;
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (a.lib) break;
@@ -1097,6 +1094,10 @@ RcclApi &rccl_api() {
         a.why = "librccl.so.1 lacks an expected symbol";
         a.lib = nullptr;
     }
+    return a;
+}
+RcclApi &rccl_api() {
+    static RcclApi a = rccl_load();  // (one load per process; the language makes the initialisation thread-safe)
     return a;
 }
 }  // namespace
