@@ -30,7 +30,7 @@ dimension) -- the launch size at which the chip, not the
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream, over whole episodes
 of fixed length whatever --steps is (see `kernel_duration`); `cpu_baseline` is the plain-C oracle (test
-infrastructure, oracle/mppi_oracle.c) timed on the host, rank 0 at N=1 only.
+infrastructure, oracle/mppi_oracle.c) timed on the host, rank 0 at N=1 only -- the only place this file touches `oracle/`.
 """
 from __future__ import annotations
 
@@ -398,7 +398,6 @@ def main():
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
     if not sharded and not c4 and not c5:
-        from oracle import mppi_oracle
         import contextlib
         import io
         state = eng.get_state()
@@ -408,7 +407,8 @@ def main():
                 t1 = time.perf_counter()
                 u0 = ctrl._calc_input_control(state)[0]
                 ts.append(time.perf_counter() - t1)
-                state = mppi_oracle.diffdrive_plant_step(state, u0, 0.1)
+                # the driver's plant on the host, DifferentialDrive.update_state (mppi_differential_drive.py:33-40)
+                state = state + 0.1 * np.array([u0[0] * np.cos(state[2]), u0[0] * np.sin(state[2]), u0[1]])
         lat = float(np.median(ts))
 
     if rank == 0:
