@@ -103,6 +103,7 @@ PROTOTYPES = {
     "mppi_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     "mppi_get_rollout_layout": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_get_host_timing": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "mppi_time_rollout_launch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]),
     "mppi_step_device_x0": (C.c_int, [_H, C.c_void_p, C.c_void_p, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_eval_state_transition": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
     "mppi_eval_clamp": (C.c_int, [_H, _D, C.c_int32, _D]),

@@ -80,6 +80,13 @@ struct mppi_handle {
     double *d_rccl_part = nullptr, *d_rccl_gath = nullptr;
     long long n_rollout_launches = 0, n_finalize_launches = 0;  // mppi_get_counters
     double t_enqueue_s = 0.0, t_loop_s = 0.0;  // mppi_get_host_timing: closed-loop calls, enqueueing / whole call
+    // closed-loop iterations replayed from a HIP graph once the waypoint index rests (closed_loop_impl)
+    bool graph_on = false;
+    std::vector<char> graph_key;      // the kernel arguments the cached graph was captured with
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // two instances, launched in turn (see closed_loop_impl)
+    hipEvent_t graph_done[2] = {nullptr, nullptr};
+    hipStream_t graph_stream = nullptr;
+    hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
     std::string err;
 };
 
@@ -207,6 +214,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->traj_per_block = tpb;
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
+    h->graph_on = getenv("MPPI_GRAPH") && atoi(getenv("MPPI_GRAPH")) != 0;  // (opt-in: see ensure_graph)
     h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64);
     h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
@@ -293,6 +301,13 @@ extern "C" int mppi_destroy(mppi_handle *h) {
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_res) hipHostFree(h->h_res);
+    for (int i = 0; i < 2; ++i) {
+        if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
+        if (h->graph_done[i]) hipEventDestroy(h->graph_done[i]);
+    }
+    if (h->graph_ev_in) hipEventDestroy(h->graph_ev_in);
+    if (h->graph_ev_out) hipEventDestroy(h->graph_ev_out);
+    if (h->graph_stream) hipStreamDestroy(h->graph_stream);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_step)
         if (e) hipEventDestroy(e);
@@ -1335,6 +1350,73 @@ extern "C" int mppi_comm_probe(mppi_handle *h, void *stream) {
     return MPPI_OK;
 }
 
+// GRAPH_SLOTS closed-loop iterations (rollout -> finalize, the device-resident plant, next x0 call) as ONE instantiated HIP
+// graph, cached per handle and re-captured when a kernel argument changes.  Replayed, an iteration costs the host a
+// 64th of a graph launch instead of two kernel launches (2.8 us each against the GPU's 4.4 us per kernel: a slower or
+// shared host core paces the eager loop, 10-12 us per iteration on such boxes of the pool), and the GPU side runs the
+// chain at 8.6-8.7 us per iteration on every box (mppi_time_rollout_launch measures exactly this).  Only iterations that
+// cannot ask for another round: frozen waypoint index, or the sequential one resting at the end of the path.
+// GRAPH_SLOTS closed-loop iterations (rollout -> finalize, the device-resident plant, next x0 call) as an instantiated HIP
+// graph, cached per handle and re-captured when a kernel argument changes.  Replayed, an iteration costs the host a
+// 64th of a graph launch instead of two kernel launches (2.8 us each against the GPU's 4.4 us per kernel: a slower or
+// shared host core paces the eager loop, 10-12 us per iteration on such boxes of the pool), and the GPU side runs the
+// chain at 8.7 us per iteration on every box (mppi_time_rollout_launch measures exactly this).  Two instances of the
+// graph are launched in turn and an instance is launched again only when its previous run has finished: several queued
+// launches of ONE instance take a slow path in the runtime (11.2 us per iteration with 19 of them queued, measured).
+// Only iterations that cannot ask for another round: frozen waypoint index, or the sequential one resting at the end of
+// the path.  OPT-IN (MPPI_GRAPH=1): on the pool's boxes the replayed loop holds 9.6-9.7 us per iteration where the eager
+// one wanders between 9.7 and 11.2, but over whole episodes (restarts, the eager traversal, re-captures when an argument
+// changes) it came out 0.1-0.4 us per iteration behind, so eager launches stay the default.  MPPI_GRAPH_SLOTS: iterations
+// per graph (experiments).
+static int graph_slots() {
+    static const int n = getenv("MPPI_GRAPH_SLOTS") ? atoi(getenv("MPPI_GRAPH_SLOTS")) : 64;
+    return n < 1 ? 1 : n;
+}
+#define GRAPH_SLOTS graph_slots()
+template <typename R>
+static bool ensure_graph(mppi_handle *h, const KParams<R> &P, const FinalizeParams &F) {
+    std::vector<char> key(sizeof(P) + sizeof(F) + 2 * sizeof(int));
+    memcpy(key.data(), &P, sizeof(P));
+    memcpy(key.data() + sizeof(P), &F, sizeof(F));
+    const int tail[2] = {h->rollout_repeats, (int)sizeof(R)};
+    memcpy(key.data() + sizeof(P) + sizeof(F), tail, sizeof(tail));
+    if (h->graph_exec[0] && key == h->graph_key) return true;
+    static const bool verbose = getenv("MPPI_GRAPH_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[mppi] capturing a graph of %d iterations\n", GRAPH_SLOTS);
+    for (int i = 0; i < 2; ++i) {
+        if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
+        h->graph_exec[i] = nullptr;
+    }
+    hipError_t e = hipSuccess;
+    if (!h->graph_stream) e = hipStreamCreateWithFlags(&h->graph_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !h->graph_ev_in) e = hipEventCreateWithFlags(&h->graph_ev_in, hipEventDisableTiming);
+    if (e == hipSuccess && !h->graph_ev_out) e = hipEventCreateWithFlags(&h->graph_ev_out, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i)
+        if (!h->graph_done[i]) e = hipEventCreateWithFlags(&h->graph_done[i], hipEventDisableTiming);
+    hipGraph_t graph = nullptr;
+    const long long l0 = h->n_rollout_launches, f0 = h->n_finalize_launches;
+    if (e == hipSuccess) e = hipStreamBeginCapture(h->graph_stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        for (int j = 0; j < GRAPH_SLOTS; ++j) launch_slot<R>(h, P, F, h->graph_stream);
+        e = hipStreamEndCapture(h->graph_stream, &graph);
+    }
+    h->n_rollout_launches = l0;  // (counted per replay)
+    h->n_finalize_launches = f0;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipGraphInstantiate(&h->graph_exec[i], graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (e != hipSuccess) {  // no graphs on this runtime: the eager loop serves
+        (void)hipGetLastError();
+        for (int i = 0; i < 2; ++i) {
+            if (h->graph_exec[i]) hipGraphExecDestroy(h->graph_exec[i]);
+            h->graph_exec[i] = nullptr;
+        }
+        h->graph_on = false;
+        return false;
+    }
+    h->graph_key.swap(key);
+    return true;
+}
+
 template <typename R>
 static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_stats *stats, hipStream_t s) {
     if (h->rccl_comm && h->x_nranks <= 1) return closed_loop_rccl<R>(h, n_iters, u0_trace, stats, s);
@@ -1361,6 +1443,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
     // While the HYPK kernels are in use the host looks in on the waypoint index after 32, 64, 128 ... slots: at the end
     // of the path (the reference driver's run reaches it after some 23 of its 1000 iterations) the lean kernels take over
     long long batch = P.hyp ? 32 : (1LL << 62);
+    int idx_now = h->idx_valid ? h->idx : -1;
     while (done < target) {
         const long long todo = target - done < batch ? target - done : batch;
         // The last slot of the batch writes its result straight into mapped host memory and publishes a sequence word
@@ -1368,15 +1451,40 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         // (14 -> 7 us of fixed cost per call).  Several agents per handle: one result per agent, copied as before.
         const bool poll = h->poll && h->B == 1;
         const double t_enq = now_s();
-        for (long long i = 0; i < todo; ++i) {
+        // the bulk of a long batch from the cached graph (see ensure_graph), the rest -- and the slot that publishes the
+        // result -- eagerly behind it, all on the graph's stream, which waits for and is waited for by the caller's
+        const bool rests = h->cfg.waypoint_mode != MPPI_WAYPOINT_SEQUENTIAL || (idx_now >= 0 && idx_now >= h->n_ref - 1);
+        hipStream_t ls = s;
+        long long i = 0;
+        if (h->graph_on && rests && !P.hyp && !u0_trace && h->x_nranks <= 1 && !timing_on(h) && todo > GRAPH_SLOTS &&
+            ensure_graph<R>(h, P, F)) {
+            ls = h->graph_stream;
+            HIPCHECK(h, hipEventRecord(h->graph_ev_in, s));
+            HIPCHECK(h, hipStreamWaitEvent(ls, h->graph_ev_in, 0));
+            const long long reps = (todo - 1) / GRAPH_SLOTS;
+            for (long long r = 0; r < reps; ++r) {
+                const int inst = (int)(r & 1);
+                if (r >= 2) HIPCHECK(h, hipEventSynchronize(h->graph_done[inst]));  // that instance's previous run is over
+                HIPCHECK(h, hipGraphLaunch(h->graph_exec[inst], ls));
+                HIPCHECK(h, hipEventRecord(h->graph_done[inst], ls));
+            }
+            i = reps * GRAPH_SLOTS;
+            h->n_rollout_launches += i * h->rollout_repeats;
+            h->n_finalize_launches += i;
+        }
+        for (; i < todo; ++i) {
             if (poll && i == todo - 1) {
                 FinalizeParams Fl = F;
                 Fl.res = h->res_mapped;
                 Fl.seq = ++h->seq;
-                launch_slot<R>(h, P, Fl, s);
+                launch_slot<R>(h, P, Fl, ls);
             } else {
-                launch_slot<R>(h, P, F, s);
+                launch_slot<R>(h, P, F, ls);
             }
+        }
+        if (ls != s) {
+            HIPCHECK(h, hipEventRecord(h->graph_ev_out, ls));
+            HIPCHECK(h, hipStreamWaitEvent(s, h->graph_ev_out, 0));
         }
         HIPCHECK(h, hipGetLastError());
         h->t_enqueue_s += now_s() - t_enq;
@@ -1394,6 +1502,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         }
         if (h->h_res->status == STATUS_PATH_END || h->h_res->status == STATUS_EXCHANGE_FAILED) break;
         done = h->h_res->iter;  // slots spent on speculation rounds did not complete an iteration
+        idx_now = h->h_res->idx_after;
         if (P.hyp) {
             if (h->B == 1 && h->h_res->idx_after >= h->n_ref - 1) {
                 P.hyp = F.hyp = 0;
@@ -1428,6 +1537,91 @@ extern "C" int mppi_run_closed_loop(mppi_handle *h, int32_t n_iters, double *u0_
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     return h->f64 ? closed_loop_impl<double>(h, n_iters, u0_trace, stats, (hipStream_t)stream)
                   : closed_loop_impl<float>(h, n_iters, u0_trace, stats, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch-to-launch duration of the rollout kernel on the GPU, with the host out of the loop (include/mppi_hip.h,
+// mppi_time_rollout_launch): n_slots closed-loop iterations captured into a HIP graph twice -- as they are, and with the
+// (idempotent) rollout kernel launched 1 + extra times per iteration -- and replayed between two events each; the
+// difference per extra launch is what one more launch of that kernel costs the stream.  Eager launches measure the same
+// on a host that keeps the queue full; on a slow or shared host core they measure the host.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+static int time_rollout_impl(mppi_handle *h, int n_slots, int extra, hipStream_t s, double *us_out) {
+    KParams<R> P = make_params<R>(h, nullptr);
+    FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 1);
+    if (P.hyp || (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && h->idx < h->n_ref - 1))
+        FAIL(h, MPPI_ERR_STATE, "mppi_time_rollout_launch: the sequential waypoint index can still move (speculation rounds "
+                                "cannot be replayed from a graph); call it once the index rests at the end of the path");
+    if (!h->dev_loop_primed) launch_set_state<R>(P, nullptr, s);
+    HIPCHECK(h, hipStreamSynchronize(s));
+    hipStream_t gs = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHECK(h, hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+    HIPCHECK(h, hipEventCreate(&e0));
+    HIPCHECK(h, hipEventCreate(&e1));
+    const int saved = h->rollout_repeats, reps = 4;
+    const long long l0 = h->n_rollout_launches, f0 = h->n_finalize_launches;
+    double ms[2] = {0.0, 0.0};
+    int rc = MPPI_OK;
+    for (int v = 0; v < 2 && rc == MPPI_OK; ++v) {
+        h->rollout_repeats = v == 0 ? 1 : 1 + extra;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            for (int j = 0; j < n_slots; ++j) launch_slot<R>(h, P, F, gs);
+            e = hipStreamEndCapture(gs, &graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e == hipSuccess) e = hipGraphLaunch(exec, gs);  // warm
+        if (e == hipSuccess) e = hipStreamSynchronize(gs);
+        const double w0 = now_s();
+        if (e == hipSuccess) e = hipEventRecord(e0, gs);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) e = hipGraphLaunch(exec, gs);
+        if (e == hipSuccess) e = hipEventRecord(e1, gs);
+        if (e == hipSuccess) e = hipStreamSynchronize(gs);
+        if (getenv("MPPI_GRAPH_VERBOSE")) fprintf(stderr, "[mppi] variant %d: wall %.2f us per iteration\n", v, 1e6 * (now_s() - w0) / (reps * n_slots));
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        ms[v] = t;
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            h->err = std::string("mppi_time_rollout_launch: ") + hipGetErrorString(e);
+            rc = MPPI_ERR_HIP;
+        }
+    }
+    h->rollout_repeats = saved;
+    h->n_rollout_launches = l0;  // (a diagnostic: the bookkeeping of the caller's runs stays as it was)
+    h->n_finalize_launches = f0;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipStreamDestroy(gs);
+    if (rc != MPPI_OK) return rc;
+    // the replays advanced the closed loop like any other run: pick the state up where they left it
+    HIPCHECK(h, hipMemcpy(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost));
+    h->iter = h->h_res->iter;
+    h->idx = h->h_res->idx_after;
+    h->dev_loop_primed = true;
+    h->last_eps = nullptr;
+    h->last_philox = true;
+    const double per = (double)reps * n_slots;
+    us_out[0] = 1e3 * (ms[1] - ms[0]) / (per * extra);
+    us_out[1] = 1e3 * ms[0] / per;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_time_rollout_launch(mppi_handle *h, int32_t n_slots, int32_t extra, void *stream, double *us_out2) {
+    int rc = check_ready(h, "mppi_time_rollout_launch");
+    if (rc) return rc;
+    if (!us_out2 || n_slots < 1 || n_slots > 4096 || extra < 1 || extra > 16)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_time_rollout_launch: n_slots 1..4096, extra 1..16");
+    if (h->x_nranks > 1 || h->rccl_comm)
+        FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_time_rollout_launch: not with an exchange between ranks (its sequence numbers cannot be replayed)");
+    HIPCHECK(h, hipSetDevice(h->cfg.device));
+    return h->f64 ? time_rollout_impl<double>(h, n_slots, extra, (hipStream_t)stream, us_out2)
+                  : time_rollout_impl<float>(h, n_slots, extra, (hipStream_t)stream, us_out2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -361,6 +361,13 @@ class Engine:
         self._ck(self.lib.mppi_get_host_timing(self._h, out))
         return {"enqueue_s": out[0], "loop_s": out[1]}
 
+    def time_rollout_launch(self, n_slots=500, extra=2, stream=None):
+        """GPU-side launch-to-launch duration of the rollout kernel (microseconds) and the in-graph iteration period, from
+        graph replays (`mppi_time_rollout_launch`): independent of how fast the host enqueues."""
+        out = (C.c_double * 2)()
+        self._ck(self.lib.mppi_time_rollout_launch(self._h, int(n_slots), int(extra), _stream_ptr(stream), out))
+        return {"rollout_us": out[0], "graph_iteration_us": out[1]}
+
     def last_kernel_ms(self):
         out = (C.c_float * 4)()
         self._ck(self.lib.mppi_last_kernel_ms(self._h, out))

@@ -329,6 +329,13 @@ int mppi_get_counters(mppi_handle *h, int64_t *out3);
  * (`host_enqueue_share`), because the iteration's 9 us leave a host that needs ~3 us per launch little slack. */
 int mppi_get_host_timing(const mppi_handle *h, double *out2);
 
+/* Launch-to-launch duration of the rollout kernel on the GPU with the host out of the loop (bench.py's `roofline.kernel_us`):
+ * `n_slots` closed-loop iterations are captured into a HIP graph as they are and with the (idempotent) rollout kernel
+ * launched 1 + `extra` times per iteration, each replayed four times between two events; us_out2 = {microseconds one more
+ * launch of the kernel costs, microseconds per iteration of the plain graph}.  The iterations are real ones (the state
+ * advances).  Needs a waypoint index that cannot move (frozen mode, or the end of the path) and no rank exchange. */
+int mppi_time_rollout_launch(mppi_handle *h, int32_t n_slots, int32_t extra, void *stream, double *us_out2);
+
 /* Which fused rollout kernel serves the handle (fixed at mppi_create from K x n_agents and T; diagnostic, for tests and
  * profiles): low two bits 0 = one sample per wave, lanes over the horizon; 1 = two samples per wave, two steps per lane
  * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128);

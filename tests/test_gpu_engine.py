@@ -786,6 +786,61 @@ def test_f32_device_closed_loop_matches_host_loop_over_a_traversal():
     assert moved >= 10 and b.prev_way_point_idx == 99  # the run did traverse the path
 
 
+@pytest.mark.parametrize("case", ["dd_sequential", "dd_frozen_batched", "racecar"])
+def test_closed_loop_from_the_cached_graph_equals_eager_launches(monkeypatch, case):
+    """With MPPI_GRAPH=1 long closed-loop calls replay their iterations from a cached HIP graph once the waypoint index
+    rests (frozen index, or the sequential one at the end of the path): the same kernels with the same arguments, so the run
+    must equal the eagerly launched one (the default) bit for bit -- across a change of the repeat count and calls too
+    short for a graph."""
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+
+    def make():
+        if case == "racecar":
+            lem = mppi_oracle.generate_lemniscate_racecar(400, 10.0)
+            c = pkg.MPPIRacecarController(ref_path=lem, horizon_step_T=30, number_of_samples_K=512,
+                                          obstacle_circles=np.array([[5.0, 5.0, 1.0]]), visualize_optimal_traj=False,
+                                          visualze_sampled_trajs=False, seed=3)
+            c._engine.set_state(lem[0].astype(np.float64))
+            return c._engine
+        if case == "dd_frozen_batched":
+            ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100)
+            e = pkg.Engine(model=capi.MODEL_DIFFDRIVE, K=256, n_agents=3, T=30, delta_t=0.1, u_max=[5.0, 3.14],
+                           param_exploration=0.05, param_lambda=1.0, param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01],
+                           stage_cost_weight=[5, 5, 10, 0], terminal_cost_weight=[5, 5, 10, 0], search_window=20,
+                           filter_window=10, clamp_rollout=1, waypoint_mode=capi.WAYPOINT_FROZEN, seed=9)
+            e.set_ref_path(ref)
+            e.set_state(np.array([[0.0, 0.0, 0.0], [0.5, -0.2, 0.1], [1.0, -0.6, -0.3]]))
+            return e
+        c = pkg.MPPIAlgorithms(**dd_kwargs(512, 30), seed=5)
+        c._engine.set_state(np.zeros(3))
+        return c._engine
+
+    def run(e):
+        out = []
+        e.run_closed_loop(60)    # (sequential index: still travelling -- eager either way)
+        e.run_closed_loop(500)   # long: graph replays + eager remainder once the index rests
+        out.append((e.get_u_prev().copy(), e.get_state().copy()))
+        e.set_rollout_repeats(2)  # other arguments: another graph
+        e.run_closed_loop(300)
+        e.set_rollout_repeats(1)
+        e.run_closed_loop(40)    # too short for a graph
+        e.run_closed_loop(200)   # the first graph again
+        out.append((e.get_u_prev().copy(), e.get_state().copy()))
+        return out, e.counters()
+
+    monkeypatch.delenv("MPPI_GRAPH", raising=False)
+    eager, c_eager = run(make())
+    monkeypatch.setenv("MPPI_GRAPH", "1")
+    graph, c_graph = run(make())
+    for (ue, xe), (ug, xg) in zip(eager, graph):
+        np.testing.assert_array_equal(ug, ue)
+        np.testing.assert_array_equal(xg, xe)
+    assert c_graph["iterations"] == c_eager["iterations"] == 1100
+    assert c_graph["rollout_launches"] == c_eager["rollout_launches"]
+    assert c_graph["finalize_launches"] == c_eager["finalize_launches"]
+
+
 def test_racecar_closed_loop_does_not_depend_on_how_it_is_chunked():
     """run(a) + run(b) == run(a + b) with the frozen waypoint index on a path that passes close to itself (the
     lemniscate's crossing): the finalize kernel has already made the next iteration's x0 call, a second one at the start
