@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: trajectory-steps/s of the MPPI iteration (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5] [--no-cpu-baseline] [--no-batched]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5] [--no-cpu-baseline] [--no-batched] [--no-graph-timing]
 
 A "step" is one closed-loop MPPI iteration (sample -> rollout -> cost -> softmin weight -> reduce ->
 filter -> shift, then the driver's plant advances the state).  Default workload `c2` = BASELINE config 2:
@@ -224,6 +224,9 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-graph-timing", action="store_true",
+                    help="skip the graph-replay measurement of the rollout launch (the profiler passes: counter collection "
+                         "and graph replays do not go together)")
     args = ap.parse_args()
     c5 = args.workload == "c5"
     if args.steps is None:
@@ -377,7 +380,7 @@ def main():
         #     instead of thousands of kernel launches, so a slow or shared host core cannot enter the figure.  At the end
         #     of the run above the waypoint index rests (hold phase / frozen index), which is what a replay needs.
         graph = None
-        if not sharded:
+        if not sharded and not args.no_graph_timing:
             try:
                 graph = eng.time_rollout_launch(20 if c5 else 500, 2, stream=stream)
             except pkg.MppiError:

@@ -9,17 +9,17 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # (the profiler passes time the headline path alone: --no-batched leaves the 32-agent block of the default line out)
-BENCH="bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-batched"
+BENCH="bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-batched --no-graph-timing"
 echo "== bench lines"; date
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_steps20.json 2>> $OUT/bench.err || echo "bench20 failed"
 echo "== kernel trace of the bench command"; date
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $BENCH > $OUT/kt.log 2>&1 || echo "kt failed"
 echo "== PMC: instruction counts"; date
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_inst -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched > $OUT/pmc_inst.log 2>&1 || echo "pmc_inst failed"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_inst -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_inst.log 2>&1 || echo "pmc_inst failed"
 echo "== PMC: HBM traffic"; date
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched > $OUT/pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched > $OUT/pmc_write.log 2>&1 || echo "pmc_write failed"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_write.log 2>&1 || echo "pmc_write failed"
 echo "== traversal only (HYPK kernels)"; date
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_trav -- python3 tools/traverse_only.py 100 > $OUT/kt_trav.log 2>&1 || echo "kt_trav failed"
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_trav -- python3 tools/traverse_only.py 20 > $OUT/pmc_trav.log 2>&1 || echo "pmc_trav failed"
