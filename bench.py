@@ -380,7 +380,9 @@ def main():
         #     instead of thousands of kernel launches, so a slow or shared host core cannot enter the figure.  At the end
         #     of the run above the waypoint index rests (hold phase / frozen index), which is what a replay needs.
         graph = None
-        if not sharded and not args.no_graph_timing:
+        under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES",
+                                                                                   "ROCPROFILER_REGISTER_FORCE_LOAD"))
+        if not sharded and not args.no_graph_timing and not under_profiler:
             try:
                 graph = eng.time_rollout_launch(20 if c5 else 500, 2, stream=stream)
             except pkg.MppiError:
