@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: trajectory-steps/s of the MPPI iteration (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5] [--no-cpu-baseline] [--no-batched] [--no-graph-timing]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5] [--no-cpu-baseline] [--no-batched] [--no-graph-timing]
 
 A "step" is one closed-loop MPPI iteration (sample -> rollout -> cost -> softmin weight -> reduce ->
 filter -> shift, then the driver's plant advances the state).  Default workload `c2` = BASELINE config 2:
@@ -81,6 +81,23 @@ def config4_kwargs(K=65536, T=75):
     return dict(ref_path=config4_path(), horizon_step_T=T, number_of_samples_K=K,
                 obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]), collision_safety_margin_rat=1.5,
                 visualize_optimal_traj=False, visualze_sampled_trajs=False)
+
+
+def config3_kwargs(K=16384, T=50):
+    """BASELINE config 3 = the `_obs` controller's `__main__` problem (mppi_differential_drive_obs.py:436-452) with 8 circles
+    (the two defaults + six drawn with default_rng(1234), none covering the start) at K=16384, T=50."""
+    rng = np.random.default_rng(1234)
+    circles = [[2.0, 2.0, 0.4], [3.0, 3.5, 0.4]]
+    while len(circles) < 8:
+        x, y = rng.uniform(0.5, 4.5, 2)
+        if x * x + y * y > 0.81:
+            circles.append([float(x), float(y), 0.4])
+    x = np.linspace(0.0, 5.0, 100)
+    return dict(delta_t=0.1, ref_path=np.array([x, x, np.arctan2(5.0, 5.0) * np.ones(100)]).T, max_speed=5.0, max_omega=3.14,
+                num_samples_K=K, num_horizons_T=T, param_exploration=0.05, param_lambda=10.0, param_alpha=0.98,
+                sigma=np.array([[0.1, 0.0], [0.0, 0.01]]), stage_cost_weight=10 * np.array([5.0, 6.0, 9.0]),
+                terminal_cost_weight=10 * np.array([5.0, 6.0, 9.0]), obstacle_circles=np.array(circles),
+                safety_margin_rate=0.8, visualize_optimal_traj=False, visualze_sampled_trajs=False)
 
 
 def config5_kwargs(K=32768, T=50):
@@ -221,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-graph-timing", action="store_true",
@@ -229,6 +246,9 @@ def main():
                          "and graph replays do not go together)")
     args = ap.parse_args()
     c5 = args.workload == "c5"
+    c3 = args.workload == "c3"
+    if c3 and args.gpus > 1:
+        raise SystemExit("--workload c3 is BASELINE's one-GPU config (sequential waypoint index: not sharded)")
     if args.steps is None:
         args.steps = 40 if c5 else 2000  # (an iteration of config 5 takes milliseconds)
     if args.warmup is None:
@@ -268,6 +288,10 @@ def main():
         weights, weights_src = config5_weights()
         make = lambda: pkg.MPPIAlgorithms(**config5_kwargs(K_global, T), precision="f32", device=local_rank, seed=2024,
                                           process_group=pg, waypoint_mode="frozen", learned_dynamics=weights)
+    elif c3:
+        K_global, T, episode, traverse = 16384, 50, EPISODE, 0
+        K_local, x_init = K_global, X_INIT
+        make = lambda: pkg.MPPIAlgorithms(**config3_kwargs(K_global, T), precision="f32", device=local_rank, seed=2024)
     elif c4:
         K_global, T, episode, traverse = 65536, 75, 100, 0  # the driver's loop runs over its 100 waypoints (:336)
         K_local = pkg.distributed.shard_range(K_global, rank, world)[1]
@@ -412,7 +436,7 @@ def main():
         host_enq = (ht1["enqueue_s"] - ht0["enqueue_s"]) / 60
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
-    if not sharded and not c4 and not c5:
+    if not sharded and not c3 and not c4 and not c5:
         import contextlib
         import io
         state = eng.get_state()
@@ -466,6 +490,7 @@ def main():
         traffic_d, traffic_src = stamped_profile("pmc_traffic", build_id)
         valu_d, valu_src = stamped_profile("pmc_valu", build_id)
         kernel_name = ("k_rollout_mlp_h3 (operands split into two f16 numbers, three v_mfma_f32_32x32x16_f16 per product)" if c5 else
+                       "k_rollout_dual<float, diffdrive + circles, 2 samples per wave / 2 steps per lane>" if c3 else
                        "k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>" if c4 else
                        "k_rollout_fused<float, diffdrive, 1 chunk, single agent, PLAIN>")
         roof = {"bound": "valu_issue", "kernel": kernel_name,
@@ -522,13 +547,16 @@ def main():
             roof["valu_issue_frac"] = None
             roof["valu_issue"] = {"source": valu_src}
         out = {"metric": "trajectory-steps/sec (KxT/iter_time), " + ("diff-drive + learned MLP dynamics K=32768 T=50" if c5 else
+                                                                     "diff-drive + 8 circular obstacles K=16384 T=50" if c3 else
                                                                      "race-car K=65536 T=75" if c4 else "diff-drive K=4096 T=50"),
                "value": units * args.steps / dt,
                "unit": "trajectory-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if (c4 or c5) else "weak",
                "vs_baseline": None, "dtype": "f32 (network products as three f16 MFMAs on split operands)" if c5 else "f32",
                "data": "synthetic",
-               "config": {"workload": ("BASELINE config 5: differential-drive with learned residual dynamics (MLP 5-512-512-512-512-3 on "
+               "config": {"workload": ("BASELINE config 3: differential-drive + 8 static circular obstacles (mppi_differential_drive_obs), "
+                                       "K=16384 x T=50 on one GPU, closed loop with the driver's plant on the device") if c3 else
+                                      ("BASELINE config 5: differential-drive with learned residual dynamics (MLP 5-512-512-512-512-3 on "
                                        "the matrix cores), K=32768 x T=50 in total, K/N per GPU, closed loop with the driver's plant "
                                        "on the device") if c5 else
                                       ("BASELINE config 4: race-car bicycle dynamics + 2 circular obstacles "
@@ -555,9 +583,9 @@ def main():
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "host_enqueue_us_per_iteration": None if host_enq is None else 1e6 * host_enq,
                "roofline": roof}
-        if world == 1 and not c4 and not c5 and not args.no_batched:
+        if world == 1 and not c3 and not c4 and not c5 and not args.no_batched:
             out["batched_agents"] = batched_agents()
-        if world == 1 and not c4 and not c5 and not args.no_cpu_baseline:  # (the C restatement timed is config 2's)
+        if world == 1 and not c3 and not c4 and not c5 and not args.no_cpu_baseline:  # (the C restatement timed is config 2's)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if sharded:

@@ -74,7 +74,7 @@ bid = build_id()
 bench = json.load(open(os.path.join(SRC, "bench.json")))
 if bench["config"]["build_id"] != bid:
     raise SystemExit(f"the profiles were taken with build {bench['config']['build_id']}, the tree is {bid}: run make_profiles.sh again")
-for f in ("bench.json", "bench_steps20.json", "bench_c4.json", "bench_c5.json", "configs.jsonl"):
+for f in ("bench.json", "bench_steps20.json", "bench_c3.json", "bench_c4.json", "bench_c5.json", "configs.jsonl"):
     copy(f, f)
 if os.path.exists(os.path.join(ROOT, "gpurun_out", "issue_cost.txt")):  # tools/issue_cost.hip, when it was run this round
     shutil.copy(os.path.join(ROOT, "gpurun_out", "issue_cost.txt"), os.path.join(DST, f"{R}_issue_cost.txt"))
