@@ -52,7 +52,8 @@ MLP_FLOP_PER_STEP = 1581056.0  # 2 x (5 x 512 + 3 x 512 x 
 EPISODE = 1000   # tSim of the reference driver (controllers/mppi_differential_drive.py:396)
 TRAVERSE = 23    # iterations the robot needs from the head of the path to its goal (measured; reported separately)
 X_INIT = np.zeros(3)  # init_x, :394
-PROFILE_ROUND = "r02"  # profiles/<round>_pmc_*.json: counter passes of the same command, stamped with the build
+PROFILE_ROUND = "r03"  # profiles/<round>_pmc.json: counter passes of the bench commands, per kernel, stamped with the build
+SHADER_GHZ = 2.07     # shader clock while the analytic rollout kernels run (clock64 against the wall clock, stamps build)
 
 
 def config2_kwargs(K=K_SAMPLES, T=HORIZON):
@@ -222,6 +223,16 @@ def cpu_baseline(budget_s=10.0, budget_all_s=6.0):
                                     "(samples independent), OpenMP over K on every core this process may use"}}
 
 
+def pmc_kernel(pmc, kernel, workgroups):
+    """Counters of ONE kernel instantiation from profiles/<round>_pmc.json (tools/collect_profiles.py): the entry whose
+    rocprofv3 name contains `kernel` and -- the same instantiation serves launches of several sizes -- whose launch had
+    `workgroups` workgroups.  None when there is none: a figure of another kernel or launch size is never quoted."""
+    if pmc is None:
+        return None
+    hits = [e for e in pmc.get("kernels", []) if kernel in e["kernel"] and e["grid"] // e["wg"] == workgroups]
+    return max(hits, key=lambda e: e.get("launches_averaged", 0)) if hits else None
+
+
 def stamped_profile(name, build_id):
     """profiles/<round>_<name>.json if it was taken with THIS build of the kernels, else (None, why)."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
@@ -233,12 +244,183 @@ def stamped_profile(name, build_id):
     return d, f"profiles/{PROFILE_ROUND}_{name}.json (build {build_id})"
 
 
+def eps_hbm_line(args):
+    """`--eps hbm`: the form of the analytic path north_star calls memory-bound -- the noise tensor of `_calc_epsilon`
+    (mppi_differential_drive.py:273-283) MATERIALISED in HBM and read by the rollout as coalesced [K, T, 2] rows, instead of
+    drawn in registers.  A ring of 8 tensors (mppi_set_noise_ring; > 256 MiB in total, so that no slot survives in the
+    Infinity Cache until it is read again) is filled once by the engine's sampler; the timed closed loop then reads one
+    slot per iteration.  Workloads: `c4` = config 4's size on one GPU (K = 65536 x T = 75, 39 MB of noise per launch);
+    `c2` = 32 batched config-2 agents (52 MB per launch: a single config-2 problem's 1.6 MB never leaves the caches).
+    The rollout launch's duration is taken with per-launch event pairs (calibrated) -- a repeated launch would re-read its
+    slot from the cache, so the marginal method of the default line does not apply -- and `traffic` from the FETCH_SIZE /
+    WRITE_SIZE passes of THIS command under profiles/.  One GPU."""
+    import torch
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    torch.cuda.set_device(0)
+    n_slots = 8
+    if args.workload == "c4":
+        K, T, n_agents, episode = 65536, 75, 1, 100
+        ctrl = pkg.MPPIRacecarController(**config4_kwargs(K, T), precision="f32", device=0, seed=2024)
+        eng, x_init = ctrl._engine, config4_path()[0].astype(np.float64)
+        restart = lambda: ctrl.restart_episode(x_init)
+        what = ("BASELINE config 4's size on one GPU: race-car + 2 circular obstacles, K=65536 x T=75, noise read from a "
+                "materialised [K,T,2] tensor in HBM")
+    else:
+        K, T, n_agents, episode = K_SAMPLES, HORIZON, 32, EPISODE
+        kw = config2_kwargs()
+        eng = pkg.Engine(model=capi.MODEL_DIFFDRIVE, K=K, T=T, delta_t=kw["delta_t"], u_max=[kw["max_speed"], kw["max_omega"]],
+                         param_exploration=kw["param_exploration"], param_lambda=kw["param_lambda"], param_alpha=kw["param_alpha"],
+                         sigma=np.asarray(kw["sigma"]).reshape(-1), stage_cost_weight=list(kw["stage_cost_weight"]) + [0.0],
+                         terminal_cost_weight=list(kw["terminal_cost_weight"]) + [0.0], search_window=20, filter_window=10,
+                         clamp_rollout=1, clamp_u_after_update=0, waypoint_mode=capi.WAYPOINT_FROZEN, seed=5, n_agents=n_agents)
+        eng.set_ref_path(kw["ref_path"])
+
+        def restart():
+            eng.set_u_prev(np.zeros((n_agents, T, 2)))
+            eng.set_waypoint_idx(0)
+            eng.set_state(np.zeros((n_agents, 3)))
+        what = ("32 independent BASELINE config-2 problems (diff-drive, K=4096 x T=50 each, frozen waypoint index) batched in "
+                "one handle, noise read from a materialised [32,K,T,2] tensor in HBM")
+    ring = torch.empty((n_slots,) + eng._lead + (K, T, 2), dtype=torch.float32, device="cuda:0")
+    for i in range(n_slots):
+        eng.sample_epsilon(i, out=ring[i])
+    torch.cuda.synchronize()
+    steps = args.steps if args.steps is not None else 400
+    warm = args.warmup if args.warmup is not None else 40
+
+    def run(n, pos=[0]):
+        while n > 0:
+            if pos[0] % episode == 0:
+                restart()
+            m = min(n, episode - pos[0] % episode)
+            eng.run_closed_loop(m)
+            pos[0] += m
+            n -= m
+
+    def timed(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    out = {}
+    for mode in ("philox", "hbm"):
+        eng.set_noise_ring(ring if mode == "hbm" else None)
+        run.__defaults__[0][0] = 0
+        run(8)
+        run(max(1, warm))
+        dt = timed(steps)
+        eng.enable_timing(True)
+        run(min(steps, 400))
+        kms = eng.last_kernel_ms()
+        eng.enable_timing(False)
+        out[mode] = {"s_per_step": dt / steps, "rollout_us": 1e3 * kms["rollout"], "finalize_us": 1e3 * kms["finalize"],
+                     "merge_us": 1e3 * kms["reduce"], "kernel": eng.rollout_kernel()}
+    units = n_agents * K * T
+    alg = (16.0 * K * T + 8.0 * K) * n_agents
+    read = 8.0 * K * T * n_agents  # what the rollout really has to fetch: one pass over the noise (the second stays in registers)
+    build_id = pkg.source_id()
+    h = out["hbm"]
+    layout = eng.counters()["rollout_layout"]
+    per_wg = 16 * (2 if (layout & 3) == 1 else 1) * (2 if layout & 4 else 1)
+    pmc, pmc_src = stamped_profile("pmc_eps_" + args.workload, build_id)
+    pk = pmc_kernel(pmc, h["kernel"], ((K + per_wg - 1) // per_wg) * n_agents) if h["kernel"] else None
+    traffic = None
+    if pk is not None and "FETCH_SIZE" in pk["counters"] and "WRITE_SIZE" in pk["counters"]:
+        traffic = (2.0 * pk["counters"]["FETCH_SIZE"] + pk["counters"]["WRITE_SIZE"]) * 1024.0
+    t_roll = 1e-6 * h["rollout_us"]
+    valu = None
+    if pk is not None and "SQ_INSTS_VALU" in pk["counters"]:
+        per_wave = pk["counters"]["SQ_INSTS_VALU"] / pk["counters"]["SQ_WAVES"]
+        issue_us = per_wave * pk["counters"]["SQ_WAVES"] / 1024.0 * 4.0 / SHADER_GHZ * 1e-3
+        valu = {"valu_instructions_per_wave": per_wave, "waves_per_simd": pk["counters"]["SQ_WAVES"] / 1024.0,
+                "issue_us": issue_us, "valu_issue_frac": min(1.0, issue_us / h["rollout_us"])}
+    line = {"metric": "trajectory-steps/sec (KxT/iter_time), noise tensor read from HBM, " + ("race-car K=65536 T=75" if args.workload == "c4" else "32 x diff-drive K=4096 T=50"),
+            "value": units / h["s_per_step"], "unit": "trajectory-steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+            "ms_per_step": 1e3 * h["s_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": what, "K_per_problem": K, "T": T, "problems_per_launch": n_agents,
+                       "noise": "ring of %d materialised tensors (%.0f MB each, %.0f MB in all), slot = iteration mod %d, "
+                                "filled by the engine's Philox sampler" % (n_slots, read / 1e6, n_slots * read / 1e6, n_slots),
+                       "build_id": build_id},
+            "roofline": {"bound": "hbm", "kernel": h["kernel"], "achieved": alg / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / t_roll / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": pmc_src if pk is not None else (pmc_src if pmc is None else pmc_src + " holds no counters of this launch"),
+                         "algorithmic_bytes_per_launch": alg, "noise_bytes_read_per_launch": read,
+                         "noise_read_GBs": read / t_roll / 1e9, "noise_read_frac_of_peak": read / t_roll / 1e9 / HBM_PEAK_GBS,
+                         "kernel_us": h["rollout_us"], "kernel_us_method": "per-launch event pairs minus the empty-pair calibration "
+                                                                           "(mppi_enable_timing), averaged over the timed launches",
+                         "valu_issue": valu,
+                         "note": "algorithmic bytes = 16 B per trajectory-step (SURVEY.md section 8d counts the reference's two "
+                                 "passes over the noise) + 8 B per trajectory; the fused kernel reads the tensor ONCE (8 B per "
+                                 "step, `noise_bytes_read_per_launch`) and keeps it in registers for the weighted sum, so the "
+                                 "bytes it really moves are half the algorithmic figure"},
+            "same_run_with_the_in_kernel_sampler": {"value": units / out["philox"]["s_per_step"], "ms_per_step": 1e3 * out["philox"]["s_per_step"],
+                                                    "rollout_kernel_us": out["philox"]["rollout_us"], "kernel": out["philox"]["kernel"]},
+            "finalize_us": h["finalize_us"], "merge_us": h["merge_us"]}
+    print(json.dumps(line))
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves -- one child process per GPU
+    running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what `torch.distributed.run` would
+    export -- relay rank 0's JSON line and fail if any rank does.  This parent never imports torch and never touches a
+    GPU (nothing that has initialised the GPU is ever re-exec'd; the children are fresh interpreters)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL and the peer-to-peer exchange need it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    chunks, rc = [], 0
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break  # a rank failed: the others would wait for it at the next barrier or exchange
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # a rank that failed (or an interrupt here) must not leave the others waiting at a barrier
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    reader.join(timeout=10)
+    out0 = "".join(c or "" for c in chunks)
+    rcs = [p.returncode for p in procs]
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    for ln in out0.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if any(rcs) or not lines:
+        print(f"bench.py: ranks exited with {rcs}" + ("" if lines else "; rank 0 printed no JSON line"), file=sys.stderr)
+        rc = next((c for c in rcs if c), 1)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--eps", choices=["philox", "hbm"], default="philox",
+                    help="hbm: the noise tensor materialised in HBM and read by the rollout (one GPU, --workload c2 = 32 batched "
+                         "config-2 agents, or c4); see eps_hbm_line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-graph-timing", action="store_true",
@@ -249,10 +431,17 @@ def main():
     c3 = args.workload == "c3"
     if c3 and args.gpus > 1:
         raise SystemExit("--workload c3 is BASELINE's one-GPU config (sequential waypoint index: not sharded)")
+    if args.eps == "hbm":
+        if args.gpus != 1 or args.workload not in ("c2", "c4"):
+            raise SystemExit("--eps hbm: one GPU, --workload c2 (32 batched agents) or c4")
+        return eps_hbm_line(args)
     if args.steps is None:
         args.steps = 40 if c5 else 2000  # (an iteration of config 5 takes milliseconds)
     if args.warmup is None:
         args.warmup = 5 if c5 else 200
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us (the driver's `python3 bench.py --gpus N ...`): start the N ranks, relay rank 0's line
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -260,6 +449,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MPPI_BENCH_LAUNCH_CHECK"):
+        # tests/test_bench_launcher.py (no GPU): the ranks the launcher started find each other and rank 0's line travels
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if os.environ["MPPI_BENCH_LAUNCH_CHECK"] == "fail" and rank == world - 1:
+            raise SystemExit(3)
+        if rank == 0:
+            print("a line that is not the result")
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps}))
+        dist.destroy_process_group()
+        return
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # rehearsal of the N>1 path on a one-GPU box: every rank on MPPI_BENCH_DEVICE, gloo instead of RCCL (which
@@ -411,7 +613,7 @@ def main():
                 graph = eng.time_rollout_launch(20 if c5 else 500, 2, stream=stream)
             except pkg.MppiError:
                 graph = None
-        kms = dict(kms, graph=graph)
+        kms = dict(kms, graph=graph, ran=eng.rollout_kernel())
         return ctrl, eng, dt, idx_timed, k1, k2, n_kernel_iters, kms, phases
 
     try:
@@ -425,15 +627,6 @@ def main():
         barrier()
         ctrl, eng, dt, idx_timed, k1, k2, n_kernel_iters, kms, phases = measure()
 
-    # what the HOST needs to enqueue one iteration's launches when nothing holds it back (a short call into an idle queue):
-    # the loop is GPU-paced only while this stays below the iteration time
-    host_enq = None
-    if not sharded:
-        barrier()
-        ht0 = eng.host_timing()
-        eng.run_closed_loop(60, stream=stream)  # (short: eager launches, below the length that replays a graph)
-        ht1 = eng.host_timing()
-        host_enq = (ht1["enqueue_s"] - ht0["enqueue_s"]) / 60
     # host-in-the-loop latency: x0 from the host, u0 back to the host every iteration
     lat = None
     if not sharded and not c3 and not c4 and not c5:
@@ -487,17 +680,33 @@ def main():
         if frac is not None and not (0.0 < frac <= 1.0):  # never report more than the roof: say what was seen instead
             method += "; REJECTED (implied %.3g of the HBM peak)" % frac
             frac, t_roll = None, None
-        traffic_d, traffic_src = stamped_profile("pmc_traffic", build_id)
-        valu_d, valu_src = stamped_profile("pmc_valu", build_id)
+        pmc, pmc_src = stamped_profile("pmc", build_id)
+        ran = kms["ran"]  # the instantiation the timed launches took, as rocprofv3 spells it
+        layout = eng.counters()["rollout_layout"]
+        # workgroups of one rollout launch: 16 waves with a sample each, or two (the dual layout: low bits == 1), or two in
+        # sequence on top (+4); the learned-dynamics kernel: 64 samples per workgroup
+        per_wg = 64 if c5 else 16 * (2 if (layout & 3) == 1 else 1) * (2 if layout & 4 else 1)
+        wgs_launch = (K_local + per_wg - 1) // per_wg
+        pk = pmc_kernel(pmc, ran, wgs_launch) if ran else None
+        pk_why = pmc_src if pk is not None else (pmc_src if pmc is None else
+                                                  f"{pmc_src} holds no counters of {ran} at {wgs_launch} workgroups per launch")
+        traffic = None
+        if pk is not None and "FETCH_SIZE" in pk["counters"] and "WRITE_SIZE" in pk["counters"]:
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts half of a wide coalesced read on gfx950 (x2), WRITE_SIZE exact; KB
+            traffic = (2.0 * pk["counters"]["FETCH_SIZE"] + pk["counters"]["WRITE_SIZE"]) * 1024.0
         kernel_name = ("k_rollout_mlp_h3 (operands split into two f16 numbers, three v_mfma_f32_32x32x16_f16 per product)" if c5 else
                        "k_rollout_dual<float, diffdrive + circles, 2 samples per wave / 2 steps per lane>" if c3 else
                        "k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>" if c4 else
                        "k_rollout_fused<float, diffdrive, 1 chunk, single agent, PLAIN>")
-        roof = {"bound": "valu_issue", "kernel": kernel_name,
+        sequential = not (sharded or c4 or c5)
+        phase = ("hold phase only (graph replays need a waypoint index at rest; the eager marginal figure beside it is "
+                 "over whole episodes)" if (t_roll is not None and t_roll == t_graph and sequential) else
+                 "whole episodes of the driver's run" + (", traversal included" if sequential else ""))
+        roof = {"bound": "valu_issue", "kernel": kernel_name, "kernel_instantiation": ran,
                 "achieved": None if t_roll is None else alg_bytes / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": frac, "hbm_frac": frac,
-                "traffic": None if traffic_d is None else traffic_d.get("hbm_bytes_per_launch"),
-                "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": pk_why, "workgroups_per_launch": wgs_launch,
+                "kernel_us_phase": phase,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": None if t_roll is None else 1e6 * t_roll, "kernel_us_method": method,
                 "kernel_us_marginal": 1e6 * t_marg, "kernel_us_event_pair": 1e6 * ev_pair,
@@ -506,7 +715,7 @@ def main():
                 "measured_over": {"iterations": n_kernel_iters, "rollout_launches": l1, "finalize_launches": f1,
                                   "rollout_launches_per_iteration": l1 / n_kernel_iters,
                                   "region_ms": {"1x_rollout": 1e3 * t1x, "2x_rollout": 1e3 * t2x}},
-                "event_pair_us": {k: 1e3 * v for k, v in kms.items() if k != "graph"},
+                "event_pair_us": {k: 1e3 * v for k, v in kms.items() if k not in ("graph", "ran")},
                 "note": "achieved/peak/frac are the ALGORITHMIC bytes of one launch over its live duration against the "
                         "HBM roof SURVEY.md section 8d nominates (hbm_frac = frac).  The roof that BINDS the launch is "
                         "VALU issue (bound): the noise is drawn in-kernel (Philox) and never touches HBM, so the PMC "
@@ -514,8 +723,8 @@ def main():
                         "waves per SIMD x 4 clocks / kernel_us, instruction counts from the PMC pass of this build "
                         "(null when no such pass is committed) -- an instruction-count model: measured issue costs on "
                         "gfx950 are 2.5 / 4.3 / 8.3 cycles by instruction class (tools/issue_cost.hip, DESIGN.md section 6), "
-                        "and dependent chains leave issue slots empty at four waves per SIMD.  Averaged over whole "
-                        "episodes of the driver's run, traversal included."}
+                        "and dependent chains leave issue slots empty at four waves per SIMD.  Counter figures are "
+                        "quoted only from a pass over THIS kernel instantiation at THIS launch size."}
         if c5:
             # the learned-dynamics rollout is bound by the matrix pipe: algorithmic flop of the network per launch (SURVEY.md
             # section 8d: 1 581 056 per trajectory-step) over the launch's duration, against the dense f16 peak.  The kernel
@@ -527,7 +736,14 @@ def main():
             roof = {"bound": "mfma", "kernel": "k_rollout_mlp (f32-input MFMA)" if f32_kernel else kernel_name,
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
                     "mfma_issue_frac": None if ach is None else (1.0 if f32_kernel else 3.0) * ach / peak,
-                    "traffic": None, "algorithmic_flop_per_launch": flop,
+                    "traffic": traffic, "traffic_source": pk_why, "algorithmic_flop_per_launch": flop,
+                    "kernel_instantiation": ran,
+                    # rocprofv3 --pmc pass of this command (profiles/): the matrix pipe's busy cycles over the launch's
+                    # cycles on all 1024 SIMDs, and the MFMA operations the counters saw against the algorithmic count
+                    "MfmaUtil": (None if pk is None or "SQ_VALU_MFMA_BUSY_CYCLES" not in pk["counters"] or
+                                 not pk["counters"].get("GRBM_GUI_ACTIVE") else
+                                 pk["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (pk["counters"]["GRBM_GUI_ACTIVE"] * 1024.0)),
+                    "pmc": None if pk is None else pk["counters"],
                     "kernel_us": None if t_roll is None else 1e6 * t_roll, "kernel_us_method": method,
                     "kernel_us_marginal": 1e6 * t_marg, "kernel_us_event_pair": 1e6 * ev_pair,
                     "kernel_us_graph": None if graph is None else graph["rollout_us"],
@@ -535,17 +751,16 @@ def main():
                     "note": "achieved = algorithmic flop of the network per launch / the launch's duration; peak = dense "
                             "f16 MFMA (the f32-input MFMA's 157.3 TFLOP/s with MPPI_MLP_F32=1); mfma_issue_frac counts "
                             "the three MFMAs the kernel issues per product.  weights: " + weights_src}
-        elif valu_d is not None and t_roll:
-            key = "config 4 shard" if c4 else "config 2"
-            v = next((x for k, x in valu_d.items() if k.startswith(key)), None)
-            if v is not None:
-                roof["valu_issue_frac"] = min(1.0, v["valu_issue_us"] / (1e6 * t_roll))
-                roof["valu_issue"] = {"valu_instructions_per_wave": v["per_wave"]["VALU"],
-                                      "waves_per_simd": v["waves_per_simd"], "issue_us": v["valu_issue_us"],
-                                      "source": valu_src}
-        if not c5 and "valu_issue_frac" not in roof:
+        elif t_roll:
             roof["valu_issue_frac"] = None
-            roof["valu_issue"] = {"source": valu_src}
+            roof["valu_issue"] = {"source": pk_why}
+            if pk is not None and "SQ_INSTS_VALU" in pk["counters"]:
+                per_wave = pk["counters"]["SQ_INSTS_VALU"] / pk["counters"]["SQ_WAVES"]
+                wps = pk["counters"]["SQ_WAVES"] / 1024.0  # 256 compute units x 4 SIMDs
+                issue_us = per_wave * wps * 4.0 / SHADER_GHZ * 1e-3
+                roof["valu_issue_frac"] = min(1.0, issue_us / (1e6 * t_roll))
+                roof["valu_issue"] = {"valu_instructions_per_wave": per_wave, "waves_per_simd": wps, "issue_us": issue_us,
+                                      "shader_clock_GHz": SHADER_GHZ, "source": pk_why, "vgprs": pk.get("vgprs")}
         out = {"metric": "trajectory-steps/sec (KxT/iter_time), " + ("diff-drive + learned MLP dynamics K=32768 T=50" if c5 else
                                                                      "diff-drive + 8 circular obstacles K=16384 T=50" if c3 else
                                                                      "race-car K=65536 T=75" if c4 else "diff-drive K=4096 T=50"),
@@ -557,7 +772,8 @@ def main():
                "config": {"workload": ("BASELINE config 3: differential-drive + 8 static circular obstacles (mppi_differential_drive_obs), "
                                        "K=16384 x T=50 on one GPU, closed loop with the driver's plant on the device") if c3 else
                                       ("BASELINE config 5: differential-drive with learned residual dynamics (MLP 5-512-512-512-512-3 on "
-                                       "the matrix cores), K=32768 x T=50 in total, K/N per GPU, closed loop with the driver's plant "
+                                       "the matrix cores), K=32768 x T=50 in total, K/N per GPU, FROZEN waypoint index (the "
+                                       "sequential one is pinned at K <= 1024 by the tests), closed loop with the driver's plant "
                                        "on the device") if c5 else
                                       ("BASELINE config 4: race-car bicycle dynamics + 2 circular obstacles "
                                        "(mppi_race_car_obstacle defaults), K=65536 x T=75 in total, K/N per GPU, closed loop "
@@ -581,7 +797,6 @@ def main():
                                    {"traverse (first %d iterations of an episode)" % traverse: 1e6 * phases["traverse"],
                                     "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
-               "host_enqueue_us_per_iteration": None if host_enq is None else 1e6 * host_enq,
                "roofline": roof}
         if world == 1 and not c3 and not c4 and not c5 and not args.no_batched:
             out["batched_agents"] = batched_agents()

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
+ABI_VERSION = 4  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
+MIN_AB_ABI_VERSION = 3  # oldest library an MPPI_LIB override may point at: same mppi_config / mppi_stats layouts as now
 LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.so")  # MPPI_LIB: A/B a diagnostic build
 
 # enums of mppi_hip.h
@@ -90,6 +91,7 @@ PROTOTYPES = {
     "mppi_get_weights": (C.c_int, [_H, _D]),
     "mppi_sample_epsilon": (C.c_int, [_H, C.c_int64, C.c_void_p, C.c_void_p]),
     "mppi_set_iteration": (C.c_int, [_H, C.c_int64]),
+    "mppi_set_noise_ring": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "mppi_rollout_viz": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mppi_set_state": (C.c_int, [_H, _D]),
     "mppi_get_state": (C.c_int, [_H, _D]),
@@ -103,6 +105,7 @@ PROTOTYPES = {
     "mppi_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     "mppi_get_rollout_layout": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_get_host_timing": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "mppi_get_rollout_kernel": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "mppi_time_rollout_launch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]),
     "mppi_step_device_x0": (C.c_int, [_H, C.c_void_p, C.c_void_p, _D, _D, C.POINTER(MppiStats), C.c_void_p]),
     "mppi_eval_state_transition": (C.c_int, [_H, _D, _D, C.c_int32, _D]),
@@ -152,6 +155,11 @@ def load_library(path: str | None = None):
         fn.restype, fn.argtypes = res, args
     if lib.mppi_abi_version() != ABI_VERSION and not ab_build:
         raise MppiError(ERR_BAD_ARG, "ABI version mismatch between _capi.py and libmppi_hip.so")
+    if ab_build and lib.mppi_abi_version() < MIN_AB_ABI_VERSION:
+        # an older diagnostic build may lack the newest entry points, but not with other struct layouts: mppi_config and
+        # mppi_stats are what they are since this version (mppi_create also compares struct_size)
+        raise MppiError(ERR_BAD_ARG, f"MPPI_LIB={p} has ABI version {lib.mppi_abi_version()}: its mppi_config / mppi_stats "
+                                     f"layouts differ from this binding's (needs >= {MIN_AB_ABI_VERSION})")
     if path is None:
         _lib = lib
     return lib

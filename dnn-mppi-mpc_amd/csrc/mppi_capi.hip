@@ -48,6 +48,7 @@ struct mppi_handle {
     long long seq = 0;
     bool poll = true, idx_valid = true, by_args_ok = true;
     int layout = 0;  // rollout_layout(K, T): which fused rollout kernel serves this handle
+    const char *rollout_kernel = "";  // the instantiation the last rollout-class launch took (mppi_get_rollout_kernel)
     MlpParams mlp;
     bool mlp_set = false;
     void *d_ref = nullptr, *d_obs = nullptr, *d_u = nullptr, *d_uhist = nullptr, *d_S = nullptr;
@@ -59,6 +60,8 @@ struct mppi_handle {
     StepResult *d_res = nullptr, *h_res = nullptr;
     size_t res_bytes = 0;
     const float *last_eps = nullptr;
+    const float *noise_ring = nullptr;  // mppi_set_noise_ring: [noise_slots][n_agents][K][T][2] device floats (caller's)
+    int noise_slots = 0;
     bool last_philox = true, begun = false, timing = false, dev_loop_primed = false, slot_timed = false;
     long long iter = 0;
     int idx = 0, rollout_repeats = 1;
@@ -397,6 +400,31 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
         h->mlp.h3_w_in = h->d_mlp16;
         for (int l = 0; l < 3; ++l) h->mlp.h3_w_h[l] = h->d_mlp16 + n_in16 + (size_t)l * n_h16;
         h->mlp.use_h3 = getenv("MPPI_MLP_F32") ? 0 : 1;
+        // The split kernel carries every WEIGHT as two f16 numbers: one beyond the f16 range (65504; e.g. W_in / in_scale with a
+        // StandardScaler scale near 1e-6) would become inf in the high plane.  Such a model takes the f32-input MFMA kernel,
+        // which has no range limit, and the handle says so (mppi_last_error; mppi_get_mlp_kernel).  Inputs and first-layer
+        // pre-activations of any magnitude are handled inside the split kernel (per-sample power-of-two scales).
+        double wmax = 0.0;
+        for (int i = 0; i < 512 * 5; ++i) wmax = fmax(wmax, fabs((double)w_in[i]));
+        for (int l = 0; l < 3; ++l)
+            for (size_t i = 0; i < (size_t)512 * 512; ++i) wmax = fmax(wmax, fabs((double)w_hidden[l][i]));
+        if (!(wmax <= 65504.0)) {  // (also NaN)
+            h->mlp.use_h3 = 0;
+            char b[256];
+            snprintf(b, sizeof(b), "mppi_set_mlp: max |weight| = %.4g exceeds the f16 range: the f32-input MFMA kernel serves this model", wmax);
+            h->err = b;
+        }
+    }
+    {   // bounds the split kernel scales the first layer's output with: |W_in z + b_in|_inf <= in_gain |z|_inf + in_bias
+        double gain = 0.0, bias = 0.0;
+        for (int n = 0; n < 512; ++n) {
+            double row = 0.0;
+            for (int j = 0; j < 5; ++j) row += fabs((double)w_in[n * 5 + j]);
+            gain = fmax(gain, row);
+            bias = fmax(bias, fabs((double)b_in[n]));
+        }
+        h->mlp.in_gain = (float)(gain * (1.0 + 1e-6));
+        h->mlp.in_bias = (float)(bias * (1.0 + 1e-6));
     }
     h->mlp_set = true;
     return MPPI_OK;
@@ -530,7 +558,10 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.clamp_rollout = c.clamp_rollout;
     P.wrap_stage = c.wrap_yaw_stage;
     P.wrap_term = c.wrap_yaw_terminal;
-    P.use_philox = eps == nullptr;
+    // this call's tensor, else the noise ring when one is set (slot = iteration mod slots, picked in the kernels), else Philox
+    const float *noise = eps ? eps : h->noise_ring;
+    P.eps_slots = eps ? 0 : (h->noise_ring ? h->noise_slots : 0);
+    P.use_philox = noise == nullptr;
     P.traj_per_block = h->traj_per_block;
     P.seed_lo = (unsigned)(c.seed & 0xffffffffu);
     P.seed_hi = (unsigned)(c.seed >> 32);
@@ -567,7 +598,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.ref = (const R *)h->d_ref;
     P.obs = (const R *)h->d_obs;
     P.u = (const R *)h->d_u;
-    P.eps = eps;
+    P.eps = noise;
     P.S = (R *)h->d_S;
     P.pout = h->d_pout;
     P.st = h->d_st;
@@ -675,6 +706,7 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
         else if (h->fused) launch_rollout_fused<R>(P, h->d_partials, s);
         else launch_rollout<R>(P, s);
     }
+    h->rollout_kernel = mlp ? mlp_kernel_name(h->mlp) : last_rollout_kernel();
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
     if (!mlp && !h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
@@ -786,12 +818,16 @@ static int host_x0_call(const mppi_handle *h, const double *x0) {
 static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
     if (seq) {
         volatile long long *flag = &h->h_res->seq;
+        // The poll saves a copy launch and a stream synchronisation (~7 us) on SHORT calls; a long batch (thousands of
+        // iterations, or config 5's milliseconds per iteration) would spin a host core for its whole duration, so after
+        // ~0.3 ms the wait is handed to the runtime (which also surfaces a failed launch).
         for (long long spins = 0; *flag != seq; ++spins) {
             __builtin_ia32_pause();
-            if (spins > 200000000LL) {  // ~ seconds: something is wrong with the launch, surface the HIP error
+            if (spins > 60000LL) {
                 HIPCHECK(h, hipStreamSynchronize(s));
                 HIPCHECK(h, hipGetLastError());
                 if (*flag != seq) FAIL(h, MPPI_ERR_HIP, "the finalize kernel never published its result");
+                break;
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1041,9 +1077,31 @@ extern "C" int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps
     if (!h || !eps_out || iteration < 0) return MPPI_ERR_BAD_ARG;
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     KParams<float> P = make_params<float>(h, nullptr);
-    launch_sample(P.seed_lo, P.seed_hi, (unsigned)iteration, h->cfg.K, h->cfg.T, h->cfg.k_offset, P.chol, eps_out,
-                  (hipStream_t)stream, (unsigned)h->cfg.noise_stream);
+    for (int a = 0; a < h->B; ++a)  // [n_agents][K][T][2]: agent a draws with stream word noise_stream + a
+        launch_sample(P.seed_lo, P.seed_hi, (unsigned)iteration, h->cfg.K, h->cfg.T, h->cfg.k_offset, P.chol,
+                      eps_out + (size_t)a * h->cfg.K * h->cfg.T * 2, (hipStream_t)stream, (unsigned)(h->cfg.noise_stream + a));
     HIPCHECK(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+extern "C" int mppi_set_noise_ring(mppi_handle *h, const float *eps_ring, int32_t n_slots) {
+    if (!h) return MPPI_ERR_BAD_ARG;
+    if (!eps_ring || n_slots == 0) {  // back to the in-kernel sampler
+        h->noise_ring = nullptr;
+        h->noise_slots = 0;
+        return MPPI_OK;
+    }
+    if (n_slots < 1 || (n_slots & (n_slots - 1)) != 0)
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_noise_ring: n_slots must be a power of two (got %d)", n_slots);
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, eps_ring) != hipSuccess || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered ||
+        at.device != h->cfg.device) {
+        (void)hipGetLastError();
+        FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_noise_ring: the ring must be device memory on the handle's GPU (device %d)", h->cfg.device);
+    }
+    h->noise_ring = eps_ring;
+    h->noise_slots = n_slots;
     return MPPI_OK;
 }
 
@@ -1307,6 +1365,26 @@ extern "C" int mppi_comm_connect(mppi_handle *h, int32_t rank, int32_t nranks, c
         if (r == rank) {
             peers[r] = h->xbuf;
         } else if (local_ptrs && local_ptrs[r]) {
+            // a peer living in this process: its buffer must be device memory, and when it sits on ANOTHER GPU this
+            // handle's device needs peer access to it (the IPC route below enables that lazily; a raw pointer does not)
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, local_ptrs[r]) != hipSuccess || at.type == hipMemoryTypeHost ||
+                at.type == hipMemoryTypeUnregistered) {
+                (void)hipGetLastError();
+                FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_comm_connect: local_ptrs[%d] is not device memory (pass the peer's mppi_comm_buffer)", r);
+            }
+            if (at.device != h->cfg.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, h->cfg.device, at.device) != hipSuccess || !can)
+                    FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_comm_connect: device %d cannot access rank %d's buffer on device %d "
+                                                  "(no peer access: use the collective carrier)", h->cfg.device, r, at.device);
+                const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    FAIL(h, MPPI_ERR_UNSUPPORTED, "mppi_comm_connect: hipDeviceEnablePeerAccess(%d) failed: %s", at.device,
+                         hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
             peers[r] = (char *)local_ptrs[r];
         } else {
             if (!handles) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_comm_connect: no handle for rank %d", r);
@@ -1318,6 +1396,9 @@ extern "C" int mppi_comm_connect(mppi_handle *h, int32_t rank, int32_t nranks, c
             peers[r] = (char *)p;
         }
     }
+    if (h->d_xpeers) { hipFree(h->d_xpeers); h->d_xpeers = nullptr; }  // (connected before: the new wiring replaces it)
+    if (h->d_xerr) { hipFree(h->d_xerr); h->d_xerr = nullptr; }
+    if (h->d_xok) { hipFree(h->d_xok); h->d_xok = nullptr; }
     HIPCHECK(h, hipMalloc((void **)&h->d_xpeers, sizeof(char *) * nranks));
     HIPCHECK(h, hipMemcpy(h->d_xpeers, peers.data(), sizeof(char *) * nranks, hipMemcpyHostToDevice));
     HIPCHECK(h, hipMalloc((void **)&h->d_xerr, sizeof(int)));
@@ -1553,13 +1634,25 @@ static int time_rollout_impl(mppi_handle *h, int n_slots, int extra, hipStream_t
     if (P.hyp || (h->cfg.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && h->idx < h->n_ref - 1))
         FAIL(h, MPPI_ERR_STATE, "mppi_time_rollout_launch: the sequential waypoint index can still move (speculation rounds "
                                 "cannot be replayed from a graph); call it once the index rests at the end of the path");
+    if (timing_on(h))
+        FAIL(h, MPPI_ERR_STATE, "mppi_time_rollout_launch: switch mppi_enable_timing off first (its events cannot be recorded "
+                                "inside a stream capture)");
     if (!h->dev_loop_primed) launch_set_state<R>(P, nullptr, s);
     HIPCHECK(h, hipStreamSynchronize(s));
-    hipStream_t gs = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHECK(h, hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
-    HIPCHECK(h, hipEventCreate(&e0));
-    HIPCHECK(h, hipEventCreate(&e1));
+    struct Scope {  // the stream and the event pair are released on every exit
+        hipStream_t gs = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scope() {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            if (gs) hipStreamDestroy(gs);
+        }
+    } sc;
+    HIPCHECK(h, hipStreamCreateWithFlags(&sc.gs, hipStreamNonBlocking));
+    HIPCHECK(h, hipEventCreate(&sc.e0));
+    HIPCHECK(h, hipEventCreate(&sc.e1));
+    const hipStream_t gs = sc.gs;
+    const hipEvent_t e0 = sc.e0, e1 = sc.e1;
     const int saved = h->rollout_repeats, reps = 4;
     const long long l0 = h->n_rollout_launches, f0 = h->n_finalize_launches;
     double ms[2] = {0.0, 0.0};
@@ -1595,9 +1688,6 @@ static int time_rollout_impl(mppi_handle *h, int n_slots, int extra, hipStream_t
     h->rollout_repeats = saved;
     h->n_rollout_launches = l0;  // (a diagnostic: the bookkeeping of the caller's runs stays as it was)
     h->n_finalize_launches = f0;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipStreamDestroy(gs);
     if (rc != MPPI_OK) return rc;
     // the replays advanced the closed loop like any other run: pick the state up where they left it
     HIPCHECK(h, hipMemcpy(h->h_res, h->d_res, h->res_bytes, hipMemcpyDeviceToHost));
@@ -1766,6 +1856,13 @@ extern "C" int mppi_get_host_timing(const mppi_handle *h, double *out2) {
 extern "C" int mppi_get_rollout_layout(const mppi_handle *h, int32_t *layout) {
     if (!h || !layout) return MPPI_ERR_BAD_ARG;
     *layout = (h->fused && h->cfg.model != MPPI_MODEL_DIFFDRIVE_MLP) ? h->layout : -1;
+    return MPPI_OK;
+}
+
+extern "C" int mppi_get_rollout_kernel(const mppi_handle *h, char *buf, int32_t n) {
+    if (!h || !buf || n < 1) return MPPI_ERR_BAD_ARG;
+    const char *nm = h->cfg.model == MPPI_MODEL_DIFFDRIVE_MLP && h->mlp_set ? mlp_kernel_name(h->mlp) : h->rollout_kernel;
+    snprintf(buf, (size_t)n, "%s", nm ? nm : "");
     return MPPI_OK;
 }
 

@@ -384,10 +384,14 @@ extern "C" int mppi_cb_eval(mppi_cb_handle *h, int32_t what, const double *state
     if (!h || !states || !actions || !out || n < 1 || (what != 0 && what != 1)) return MPPI_ERR_BAD_ARG;
     CB_HIP(h, hipSetDevice(h->cfg.device));
     const int nx = h->P.nx, nu = h->P.nu, n_out = what == 0 ? nx : 1;
-    float *ds = nullptr, *du = nullptr, *dout = nullptr;
-    CB_HIP(h, hipMalloc((void **)&ds, sizeof(float) * (size_t)n * nx));
-    CB_HIP(h, hipMalloc((void **)&du, sizeof(float) * (size_t)n * nu));
-    CB_HIP(h, hipMalloc((void **)&dout, sizeof(float) * (size_t)n * n_out));
+    struct Scratch {  // released on every exit, the early ones of CB_HIP included
+        float *p = nullptr;
+        ~Scratch() { if (p) hipFree(p); }
+    } s_ds, s_du, s_dout;
+    CB_HIP(h, hipMalloc((void **)&s_ds.p, sizeof(float) * (size_t)n * nx));
+    CB_HIP(h, hipMalloc((void **)&s_du.p, sizeof(float) * (size_t)n * nu));
+    CB_HIP(h, hipMalloc((void **)&s_dout.p, sizeof(float) * (size_t)n * n_out));
+    float *ds = s_ds.p, *du = s_du.p, *dout = s_dout.p;
     int rc = cb_io(h, ds, nullptr, states, (size_t)n * nx);
     if (!rc) rc = cb_io(h, du, nullptr, actions, (size_t)n * nu);
     if (!rc) {
@@ -395,9 +399,6 @@ extern "C" int mppi_cb_eval(mppi_cb_handle *h, int32_t what, const double *state
         if (hipDeviceSynchronize() != hipSuccess) rc = MPPI_ERR_HIP;
     }
     if (!rc) rc = cb_io(h, dout, out, nullptr, (size_t)n * n_out);
-    hipFree(ds);
-    hipFree(du);
-    hipFree(dout);
     return rc;
 }
 
@@ -406,12 +407,15 @@ extern "C" int mppi_cb_nominal_trajectory(mppi_cb_handle *h, const double *state
     CB_HIP(h, hipSetDevice(h->cfg.device));
     float st[CB_NX] = {0, 0, 0, 0, 0};
     for (int i = 0; i < h->P.nx; ++i) st[i] = (float)state[i];
-    float *dt = nullptr;
-    CB_HIP(h, hipMalloc((void **)&dt, sizeof(float) * (size_t)h->P.T * h->P.nx));
+    struct Scratch {
+        float *p = nullptr;
+        ~Scratch() { if (p) hipFree(p); }
+    } s_dt;
+    CB_HIP(h, hipMalloc((void **)&s_dt.p, sizeof(float) * (size_t)h->P.T * h->P.nx));
+    float *dt = s_dt.p;
     CB_HIP(h, hipMemcpy(h->d_state, st, sizeof(st), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_cb_nominal, dim3(1), dim3(64), 0, nullptr, h->P, h->d_U, h->d_state, dt);
     int rc = hipDeviceSynchronize() == hipSuccess ? MPPI_OK : MPPI_ERR_HIP;
     if (!rc) rc = cb_io(h, dt, traj, nullptr, (size_t)h->P.T * h->P.nx);
-    hipFree(dt);
     return rc;
 }

@@ -116,6 +116,14 @@ __device__ __forceinline__ int nearest_uniform(const R *__restrict__ ref, int c,
     return c + bj;
 }
 
+// the noise tensor [K][T][2] of (iteration, agent): the caller's tensor of this call, or the slot of a noise ring
+// (mppi_set_noise_ring: `_calc_epsilon` materialised for a closed loop; eps_slots is a power of two)
+template <typename R> __device__ __forceinline__ const float *eps_tensor(const KParams<R> &P, unsigned iter, int agent) {
+    size_t tensor = (size_t)agent;
+    if (P.eps_slots > 0) tensor += (size_t)(iter & (unsigned)(P.eps_slots - 1)) * (size_t)(P.n_agents > 1 ? P.n_agents : 1);
+    return P.eps + tensor * ((size_t)P.K * (size_t)P.T * 2);
+}
+
 template <typename R> __device__ __forceinline__ int window_len(int window, int n_ref, int c) {
     const int rem = n_ref - c;
     return rem < window ? rem : window;

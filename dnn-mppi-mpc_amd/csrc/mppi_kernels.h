@@ -93,7 +93,9 @@ template <typename R> struct KParams {
     const R *ref;      // [n_ref][4]  x, y, yaw, v
     const R *obs;      // [n_obs][4]  x, y, threshold^2, 0
     const R *u;        // [T][2] nominal controls
-    const float *eps;  // [K][T][2] or nullptr (Philox)
+    const float *eps;  // [K][T][2] or nullptr (Philox); with eps_slots > 0: a ring [eps_slots][n_agents][K][T][2]
+    int eps_slots;     // 0: `eps` is this call's tensor; 2^n: iteration i reads slot i mod eps_slots (mppi_set_noise_ring)
+    int pad_eps;
     R *S;              // [K]
     int *pout;         // [K] waypoint index after sample k (sequential mode)
     DevState *st;
@@ -162,6 +164,9 @@ struct MlpParams {
     int use_h3;
     const unsigned short *h3_w_in;   // [2][16][1][64][8]
     const unsigned short *h3_w_h[3]; // [2][16][32][64][8]
+    // |W_in z + b_in|_inf <= in_gain |z|_inf + in_bias: the split kernel derives the per-sample power-of-two scale of the
+    // first layer's output from it, so that no f16 half overflows whatever the magnitude of the inputs
+    float in_gain, in_bias;
 };
 
 struct VizParams {
@@ -179,6 +184,8 @@ template <typename R> void launch_reduce(const KParams<R> &P, void *partials, in
 // rollout + cost + per-block softmin partial in one launch (T <= 128); fused_blocks(K) records
 template <typename R> void launch_rollout_fused(const KParams<R> &P, void *partials, hipStream_t s);
 bool fused_supported(int T);
+// the instantiation this thread's last rollout-class launch took, as rocprofv3 spells it ("k_rollout_dual<float, 1, 1, false, 2, true>")
+const char *last_rollout_kernel();
 // Which fused rollout kernel serves (K, T): decided ONCE per handle (it reads the MPPI_DUAL / MPPI_PAIR / MPPI_SEQ
 // overrides) and carried in KParams::layout, so that a launch costs no environment lookups.
 enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
@@ -223,6 +230,7 @@ void launch_eval_mlp(const KParams<float> &P, const MlpParams &Q, const float *x
 void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
                     float *opt, float *smp, hipStream_t s);
 int mlp_blocks(int K);
+const char *mlp_kernel_name(const MlpParams &Q);  // as rocprofv3 spells the rollout kernel that serves Q
 void pack_linear(const float *w, int n_in, float *packed);  // host: [512][n_in] -> fragment order
 void pack_linear_h3(const float *w, int n_in, unsigned short *packed);  // host: -> two f16 planes in fragment order
 constexpr int MODEL_DIFF_MLP = 2;

@@ -14,6 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <string>
 
 #include "mppi_device.h"
 
@@ -126,7 +130,7 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
                 px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1,
                            (unsigned)(P.noise_stream + agent));
             } else {
-                const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
+                const float2 e = *reinterpret_cast<const float2 *>(eps_tensor(P, iter, agent) + ((size_t)k * P.T + t) * 2);
                 e0 = e.x;
                 e1 = e.y;
             }
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
             px::box_muller(r[2], r[3], P.chol, e10, e11);
             if (!a1) { e10 = 0.f; e11 = 0.f; }
         } else {
-            const float *pe = P.eps + ((size_t)k * T + t0) * 2;
+            const float *pe = eps_tensor(P, iter, agent) + ((size_t)k * T + t0) * 2;
             const float2 ea = *reinterpret_cast<const float2 *>(pe);
             e00 = ea.x;
             e01 = ea.y;
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
                 if (P.use_philox) {
                     px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k0 + i + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
                 } else {
-                    const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)(k0 + i) * P.T + t) * 2);
+                    const float2 e = *reinterpret_cast<const float2 *>(eps_tensor(P, iter, 0) + ((size_t)(k0 + i) * P.T + t) * 2);
                     e0 = e.x;
                     e1 = e.y;
                 }
@@ -1819,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_viz(const KParams<R> P, const R *__rest
                 if (P.use_philox) {
                     px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(row + P.k_offset), tc, P.chol, e0, e1, (unsigned)P.noise_stream);
                 } else {
-                    const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)row * P.T + tc) * 2);
+                    const float2 e = *reinterpret_cast<const float2 *>(eps_tensor(P, iter, 0) + ((size_t)row * P.T + tc) * 2);
                     e0 = e.x;
                     e1 = e.y;
                 }
@@ -1975,6 +1979,26 @@ __global__ __launch_bounds__(64) void k_set_state_dev(const R *ref, int n_ref, i
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// Which instantiation the last rollout launch of this thread took, spelled as rocprofv3 prints it (bench.py looks its
+// counters up by this name): one static string per launch site, a pointer store per launch.
+static thread_local const char *g_last_rollout_kernel = "";
+const char *last_rollout_kernel() { return g_last_rollout_kernel; }
+template <typename R> static const char *type_name() { return sizeof(R) == 8 ? "double" : "float"; }
+static std::string kernel_name(const char *fmt, ...) {
+    char b[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof(b), fmt, ap);
+    va_end(ap);
+    return b;
+}
+#define MPPI_NOTE_KERNEL(...)                                       \
+    do {                                                            \
+        static const std::string _nm = kernel_name(__VA_ARGS__);    \
+        g_last_rollout_kernel = _nm.c_str();                        \
+    } while (0)
+static const char *tf(bool b) { return b ? "true" : "false"; }
+
 int reduce_blocks(int K, int traj_per_block) { return (K + traj_per_block - 1) / traj_per_block; }
 
 template <typename R> void launch_set_state(const KParams<R> &P, const double *x, hipStream_t s) {
@@ -1987,10 +2011,13 @@ template <typename R> void launch_set_state(const KParams<R> &P, const double *x
 
 template <typename R> void launch_rollout(const KParams<R> &P, hipStream_t s) {
     const int waves_per_block = 4, blocks = (P.K + waves_per_block - 1) / waves_per_block;
-    if (P.model == MODEL_DIFF)
+    if (P.model == MODEL_DIFF) {
+        MPPI_NOTE_KERNEL("k_rollout<%s, 0>", type_name<R>());
         hipLaunchKernelGGL((k_rollout<R, MODEL_DIFF>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P.st, P);
-    else
+    } else {
+        MPPI_NOTE_KERNEL("k_rollout<%s, 1>", type_name<R>());
         hipLaunchKernelGGL((k_rollout<R, MODEL_RACE>), dim3(blocks), dim3(64 * waves_per_block), 0, s, P.st, P);
+    }
 }
 
 bool fused_supported(int T) { return T <= 128; }
@@ -2041,8 +2068,12 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
     const bool plain_ok = P.use_philox && P.clamp_rollout && (bool)P.wrap_stage == race && (bool)P.wrap_term == race;
     const bool plain_dual = !MULTI && plain_ok;
     switch (P.layout & LAYOUT_KIND) {
-#define MPPI_LAUNCH_DUAL(SPW_, SEQ_, PLAIN_) \
-    hipLaunchKernelGGL((k_rollout_dual<R, MODEL, SPW_, MULTI, SEQ_, PLAIN_>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials)
+#define MPPI_LAUNCH_DUAL(SPW_, SEQ_, PLAIN_)                                                                                  \
+    do {                                                                                                                      \
+        MPPI_NOTE_KERNEL("k_rollout_dual<%s, %d, %d, %s, %d, %s>", type_name<R>(), MODEL, SPW_, tf(MULTI), SEQ_, tf(PLAIN_)); \
+        hipLaunchKernelGGL((k_rollout_dual<R, MODEL, SPW_, MULTI, SEQ_, PLAIN_>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, \
+                           partials);                                                                                         \
+    } while (0)
     case LAYOUT_DUAL:
         if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(2, 2, !MULTI); else MPPI_LAUNCH_DUAL(2, 1, !MULTI); }
         else if (MULTI && plain_ok && !twice) MPPI_LAUNCH_DUAL(2, 1, true);
@@ -2058,10 +2089,16 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
             const bool plain = P.obstacle_model == OBS_NONE && P.use_philox && P.clamp_rollout && !P.wrap_stage && !P.wrap_term;
             const int spec = plain ? 2 : P.obstacle_model == OBS_NONE ? 1 : 0;
             const dim3 block(64 * FUSED_WAVES);
-#define MPPI_LAUNCH_FUSED(NCH_, SPEC_) \
-    hipLaunchKernelGGL((k_rollout_fused<R, MODEL, NCH_, MULTI, SPEC_>), grid, block, 0, s, P.st, P, partials)
-#define MPPI_LAUNCH_FUSED_HYP(SPEC_) \
-    hipLaunchKernelGGL((k_rollout_fused<R, MODEL_DIFF, 1, false, SPEC_, true>), grid, block, 0, s, P.st, P, partials)
+#define MPPI_LAUNCH_FUSED(NCH_, SPEC_)                                                                                  \
+    do {                                                                                                                \
+        MPPI_NOTE_KERNEL("k_rollout_fused<%s, %d, %d, %s, %d, false>", type_name<R>(), MODEL, NCH_, tf(MULTI), SPEC_);  \
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL, NCH_, MULTI, SPEC_>), grid, block, 0, s, P.st, P, partials);      \
+    } while (0)
+#define MPPI_LAUNCH_FUSED_HYP(SPEC_)                                                                                        \
+    do {                                                                                                                    \
+        MPPI_NOTE_KERNEL("k_rollout_fused<%s, 0, 1, false, %d, true>", type_name<R>(), SPEC_);                              \
+        hipLaunchKernelGGL((k_rollout_fused<R, MODEL_DIFF, 1, false, SPEC_, true>), grid, block, 0, s, P.st, P, partials);  \
+    } while (0)
             if (P.hyp && P.T <= 64 && !MULTI && MODEL == MODEL_DIFF) {
                 if (spec == 2) MPPI_LAUNCH_FUSED_HYP(2);
                 else if (spec == 1) MPPI_LAUNCH_FUSED_HYP(1);

@@ -122,7 +122,7 @@ __device__ __forceinline__ void mlp_controls(const KParams<float> &P, unsigned i
     if (valid) {
         if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
         else {
-            const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
+            const float2 e = *reinterpret_cast<const float2 *>(eps_tensor(P, iter, 0) + ((size_t)k * P.T + t) * 2);
             e0 = e.x;
             e1 = e.y;
         }
@@ -174,7 +174,7 @@ __device__ __forceinline__ void mlp_controls_viz(const KParams<float> &P, const 
         float e0, e1;
         if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, V.iter, (unsigned)(k + P.k_offset), tc, P.chol, e0, e1, (unsigned)P.noise_stream);
         else {
-            const float2 e = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + tc) * 2);
+            const float2 e = *reinterpret_cast<const float2 *>(eps_tensor(P, V.iter, 0) + ((size_t)k * P.T + tc) * 2);
             e0 = e.x;
             e1 = e.y;
         }
@@ -251,7 +251,7 @@ __device__ __forceinline__ void mlp_record(const KParams<float> &P, float *__res
         if (valid) {
             if (P.use_philox) px::sample(P.seed_lo, P.seed_hi, iter, (unsigned)(k + P.k_offset), t, P.chol, e0, e1, (unsigned)P.noise_stream);
             else {
-                const float2 ee = *reinterpret_cast<const float2 *>(P.eps + ((size_t)k * P.T + t) * 2);
+                const float2 ee = *reinterpret_cast<const float2 *>(eps_tensor(P, iter, 0) + ((size_t)k * P.T + t) * 2);
                 e0 = ee.x;
                 e1 = ee.y;
             }
@@ -359,6 +359,25 @@ constexpr int H3_PITCH = 520, H3_ZPITCH = 24, H3_STEPS = MLP_H / 16;
 __device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+
+// The f16 range.  The input layer has no activation (train/train_diff_mlp.py:32), so raw [x, y, yaw, v, w] and the first
+// layer's output h0 = W_in z + b_in travel through f16 halves at whatever magnitude the caller's coordinates have (a path in
+// UTM metres: 1e5 .. 1e7): beyond 65504 a half is inf.  Per sample and step two powers of two keep every half below 2^15:
+// z is split as z / s0, s0 = 2^max(0, exponent(|z|_inf) - 14), and h0 as h0 / s1 with s1 from the bound
+// |h0|_inf <= in_gain |z|_inf + in_bias (host, mppi_set_mlp); the epilogues multiply the f32 accumulators back
+// (store_layer_h3).  Exact scalings: only the absolute resolution of the low halves (2^-25) grows with them.  After the first
+// tanh everything lies in [-1, 1].  s0 = s1 = 1 whenever |z|_inf < 2^15 and the bound stays below 2^15.
+struct H3Scale { float s0, inv_s0, s1, inv_s1; };
+__device__ __forceinline__ H3Scale h3_scale(const float (&z)[5], float in_gain, float in_bias) {
+    const float zmax = fmaxf(fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))), fabsf(z[4]));
+    auto pow2_over = [](float m) {  // e = max(0, exponent(m) - 14): m / 2^e < 2^15
+        const int e = max(0, (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127 - 14);
+        return min(e, 100);  // (inf / NaN inputs stay what they are)
+    };
+    const int e0 = pow2_over(zmax), e1 = pow2_over(in_gain * zmax + in_bias);
+    auto p2 = [](int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); };
+    return H3Scale{p2(e0), p2(-e0), p2(e1), p2(-e1)};
 }
 
 // acc[pass][rt][c2] = (A[64, 16 n_steps] @ W^T)^T for this wave's 128 columns (column tile ct = 2 pass + c2), i.e. the MFMA's
@@ -552,9 +571,19 @@ using half4v = __attribute__((ext_vector_type(4))) _Float16;
 // all -- every lane multiplies its 64 features of a sample by the output weights as they leave the tanh (f32, `yo[rt][j]`),
 // and the caller adds up the two lane halves and the four waves.  (Reading them back from LDS on the vector unit took 6 %
 // of the launch, splitting and storing them another 2 %.)
-template <bool TANH, bool LAST = false>
+// SCALE (the f16 range, see H3Scale): 0 none; 1 the input layer -- its accumulators are those of z / s0 and its output is
+// stored as h0 / s1: v = (acc s0 + b) / s1; 2 the first hidden layer -- its accumulators are those of h0 / s1: v = acc s1 + b.
+// `scale`: the per-sample {s0, 1 / s1, s1, 0} in LDS.  All three are 1 unless an input exceeds 2^15, and then exact powers
+// of two: the common case is bit for bit the unscaled arithmetic.
+template <bool TANH, bool LAST = false, int SCALE = 0>
 __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[2][2][2], const float *bias,
-                                               int wid, int lane, const float *w_out = nullptr, float (*yo)[3] = nullptr) {
+                                               int wid, int lane, const float *w_out = nullptr, float (*yo)[3] = nullptr,
+                                               const float *scale = nullptr) {
+    F4 sc[2] = {{{1.f, 1.f, 1.f, 0.f}}, {{1.f, 1.f, 1.f, 0.f}}};
+    if (SCALE != 0) {
+        sc[0] = *reinterpret_cast<const F4 *>(scale + 4 * (lane & 31));
+        sc[1] = *reinterpret_cast<const F4 *>(scale + 4 * (32 + (lane & 31)));
+    }
     const int lane_off = (lane & 31) * H3_PITCH + wid * 128 + 4 * (lane >> 5);
     _Float16 *const base[2][2] = {{a_hi + lane_off, a_hi + 32 * H3_PITCH + lane_off},
                                   {a_lo + lane_off, a_lo + 32 * H3_PITCH + lane_off}};
@@ -580,7 +609,12 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
         for (int rt = 0; rt < 2; ++rt) {
             f32x2 v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = f32x2{acc[ct >> 1][rt][ct & 1][2 * i], acc[ct >> 1][rt][ct & 1][2 * i + 1]} + bn[i];
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 a = f32x2{acc[ct >> 1][rt][ct & 1][2 * i], acc[ct >> 1][rt][ct & 1][2 * i + 1]};
+                if (SCALE == 1) v[i] = (a * sc[rt].v[0] + bn[i]) * sc[rt].v[1];
+                else if (SCALE == 2) v[i] = a * sc[rt].v[2] + bn[i];
+                else v[i] = a + bn[i];
+            }
             if (TANH) {  // 1 - 2 / (exp(2x) + 1), exp(2x) = 2^(x * 2 log2(e))
                 f32x2 e[8];
 #pragma unroll
@@ -649,7 +683,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     _Float16 *z_hi = a_lo + MLP_M * H3_PITCH;              // [64][24] layer-0 input rows {x, y, yaw, v, w, 0 ...}: one k-step
     _Float16 *z_lo = z_hi + MLP_M * H3_ZPITCH;
     float *ypart = reinterpret_cast<float *>(z_lo + MLP_M * H3_ZPITCH);  // [4][64][4]
-    float *ref_lds = ypart + MLP_WAVES * MLP_M * 4;                     // [n_ref][4] when the path fits
+    float *zscale = ypart + MLP_WAVES * MLP_M * 4;                      // [64][4] per-sample {s0, 1 / s1, s1, 0} (H3Scale)
+    float *ref_lds = zscale + MLP_M * 4;                                // [n_ref][4] when the path fits
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = ((int)blockIdx.x + (VIZ ? V.block0 : 0)) * MLP_M, k = k0 + lane;
     const KParams<float> PL = mlp_stage_path(P, ref_lds);
@@ -679,14 +714,16 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             } else if (VIZ) mlp_controls_viz(P, V, k, t, smp_row, opt_row, exploit, v0, v1);
             else mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
             const float z[5] = {L.x, L.y, L.yaw, v0, v1};
+            const H3Scale hs = h3_scale(z, Q.in_gain, Q.in_bias);
+            *reinterpret_cast<F4 *>(zscale + 4 * lane) = F4{{hs.s0, hs.inv_s1, hs.s1, 0.f}};
 #pragma unroll
-            for (int q = 0; q < 5; ++q) split_h3(z[q], z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
+            for (int q = 0; q < 5; ++q) split_h3(z[q] * hs.inv_s0, z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
         }
         __syncthreads();
         PH(0);
         gemm_input_h3(acc, z_hi, z_lo, Q.h3_w_in, wid, lane);
         PH(1);
-        store_layer_h3<false>(a_hi, a_lo, acc, Q.b_in, wid, lane);
+        store_layer_h3<false, false, 1>(a_hi, a_lo, acc, Q.b_in, wid, lane, nullptr, nullptr, zscale);
         H3Ring ring;
         h3_prime_layer(Q.h3_w_h[0], wid, lane, ring);
         PH(2);
@@ -697,7 +734,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             PH(4);
             __syncthreads();
             PH(5);
-            store_layer_h3<true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
+            if (l == 0) store_layer_h3<true, false, 2>(a_hi, a_lo, acc, Q.b_h[l], wid, lane, nullptr, nullptr, zscale);
+            else store_layer_h3<true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
             h3_prime_layer(Q.h3_w_h[l + 1], wid, lane, ring);
             PH(6);
             __syncthreads();
@@ -757,7 +795,7 @@ int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
 static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *partials, const MlpViz *viz, hipStream_t s) {
     const size_t ref_lds = sizeof(float) * 4 * MLP_REF_LDS_MAX;  // the path (mlp_stage_path)
     const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4) + ref_lds;
-    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * MLP_WAVES * MLP_M * 4 + ref_lds;
+    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * (MLP_WAVES + 1) * MLP_M * 4 + ref_lds;
     // (the attribute belongs to the device's copy of the code object: one process may drive several GPUs)
     static bool attr_set[64] = {};
     int dev = 0;
@@ -782,6 +820,7 @@ static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *pa
         hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
 }
 
+const char *mlp_kernel_name(const MlpParams &Q) { return Q.use_h3 ? "k_rollout_mlp_h3<false>" : "k_rollout_mlp("; }
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
     launch_mlp_any(P, Q, partials, nullptr, s);
 }

@@ -263,11 +263,30 @@ class Engine:
         return w
 
     def sample_epsilon(self, iteration, out=None, stream=None):
+        """The sampler's noise of `iteration` as a tensor: float32 [K,T,2] ([n_agents,K,T,2] for a batched handle)."""
         import torch
+        shape = self._lead + (self.K, self.T, 2)
         if out is None:
-            out = torch.empty((self.K, self.T, 2), dtype=torch.float32, device=f"cuda:{self.cfg.device}")
+            out = torch.empty(shape, dtype=torch.float32, device=f"cuda:{self.cfg.device}")
+        elif out.dtype != torch.float32 or tuple(out.shape) != shape:
+            raise ValueError(f"out must be float32 {list(shape)}")
         self._ck(self.lib.mppi_sample_epsilon(self._h, int(iteration), _dev_ptr(out), _stream_ptr(stream)))
         return out
+
+    def set_noise_ring(self, ring):
+        """`_calc_epsilon` materialised for the closed loop: ``ring`` = CUDA float32 [n_slots, (n_agents,) K, T, 2], n_slots a
+        power of two; iteration i reads slot i mod n_slots.  ``None`` returns to the in-kernel sampler.  The engine keeps a
+        reference to the tensor."""
+        if ring is None:
+            self._ck(self.lib.mppi_set_noise_ring(self._h, None, 0))
+            self._noise_ring = None
+            return
+        import torch
+        want = self._lead + (self.K, self.T, 2)
+        if ring.dtype != torch.float32 or tuple(ring.shape[1:]) != want:
+            raise ValueError(f"the noise ring must be float32 [n_slots, {', '.join(map(str, want))}]")
+        self._ck(self.lib.mppi_set_noise_ring(self._h, _dev_ptr(ring), int(ring.shape[0])))
+        self._noise_ring = ring
 
     def rollout_viz(self, want_optimal=True, want_sampled=True, stream=None):
         import torch
@@ -354,6 +373,14 @@ class Engine:
         if hasattr(self.lib, "mppi_get_rollout_layout"):  # (absent from an older diagnostic build under MPPI_LIB)
             self._ck(self.lib.mppi_get_rollout_layout(self._h, C.byref(layout)))
         return {"iterations": out[0], "rollout_launches": out[1], "finalize_launches": out[2], "rollout_layout": layout.value}
+
+    def rollout_kernel(self):
+        """Name of the kernel instantiation the last rollout-class launch took, as rocprofv3 prints it."""
+        if not hasattr(self.lib, "mppi_get_rollout_kernel"):  # (an older diagnostic build under MPPI_LIB)
+            return ""
+        buf = C.create_string_buffer(192)
+        self._ck(self.lib.mppi_get_rollout_kernel(self._h, buf, 192))
+        return buf.value.decode()
 
     def host_timing(self):
         """Seconds this handle's closed-loop calls spent enqueueing launches / inside the calls (cumulative)."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 3
+#define MPPI_ABI_VERSION 4
 
 typedef enum {
     MPPI_OK = 0,
@@ -160,6 +160,10 @@ int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m);
  * checkpoint's own layout (saved_models/mlp_diff_300x100_3l.pth): input_layer.weight [512,5], .bias [512];
  * hidden_layer.{0,1,2}.weight [512,512], .bias [512]; out_layer.weight [3,512], .bias [3].
  * hidden must be 512 and n_hidden 3 (the architecture the reference trains).
+ * Numeric range: the default kernel carries weights, inputs and activations as pairs of f16 numbers.  Inputs [x, y, yaw, v, w]
+ * and first-layer pre-activations of ANY finite magnitude are handled (per-sample power-of-two scales inside the kernel); a
+ * WEIGHT beyond +-65504 cannot be, so such a model is served by the f32-input MFMA kernel instead (about 3x slower, same
+ * results to the tolerance of the tests); mppi_last_error then says so and mppi_get_rollout_kernel returns "k_rollout_mlp(".
  */
 int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, const float *w_in, const float *b_in,
                  const float *const *w_hidden, const float *const *b_hidden, const float *w_out, const float *b_out);
@@ -222,7 +226,9 @@ int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, mppi_stats *
  * exchange buffer in fine-grained device memory; `export` creates it and returns its IPC handle
  * (mppi_comm_handle_bytes() bytes), the caller passes the handles of all ranks around once (any host
  * channel, e.g. torch.distributed.all_gather_object) and `connect` maps them (entries of `local_ptrs`
- * that are non-NULL are used as they are: peers living in the same process, see `mppi_comm_buffer`).
+ * that are non-NULL are used as they are: peers living in the same process, see `mppi_comm_buffer`; such a
+ * pointer must be device memory, and when it lives on another GPU `connect` enables peer access to that GPU --
+ * MPPI_ERR_UNSUPPORTED when it is not device memory or the two GPUs cannot reach each other).
  * From then on mppi_step and mppi_run_closed_loop exchange the per-rank record inside the finalize
  * kernel: store into every peer's buffer, raise a flag, wait for all flags -- no host call and no
  * collective launch per iteration.  Every rank must make the same sequence of step / closed-loop /
@@ -255,8 +261,20 @@ int mppi_comm_init(mppi_handle *h, const void *unique_id, int32_t rank, int32_t 
 /* S[K] of the last iteration (`S`, :103) and its weights (`_compute_weight`, :167-180); host doubles */
 int mppi_get_costs(mppi_handle *h, double *S);
 int mppi_get_weights(mppi_handle *h, double *w);
-/* the noise the sampler produces for `iteration` (`_calc_epsilon`, :273-283): device float[K,T,2] */
+/* the noise the sampler produces for `iteration` (`_calc_epsilon`, :273-283): device float[K,T,2]
+ * ([n_agents,K,T,2] for a batched handle: agent a's tensor follows agent a-1's) */
 int mppi_sample_epsilon(mppi_handle *h, int64_t iteration, float *eps_out, void *stream);
+/*
+ * `_calc_epsilon` materialised for the calls that take no tensor of their own (mppi_run_closed_loop, and mppi_step /
+ * mppi_step_begin with eps == NULL): a ring of `n_slots` noise tensors in DEVICE memory, float[n_slots][n_agents][K][T][2];
+ * iteration i (the handle's iteration counter, see mppi_set_iteration) reads slot i mod n_slots, picked inside the kernels,
+ * so a closed loop on the device replays a recorded noise sequence -- and the rollout reads its noise as coalesced rows from
+ * HBM (the reference's second pass over eps, :132-135, stays in registers).  n_slots must be a power of two; the caller owns
+ * the ring and keeps it alive; eps_ring == NULL or n_slots == 0 returns to the in-kernel Philox sampler.  A ring filled by
+ * mppi_sample_epsilon(h, i, ring + i * n_agents * K * T * 2) for i = 0 .. n_slots-1 reproduces the sampler's run over those
+ * iterations bit for bit.
+ */
+int mppi_set_noise_ring(mppi_handle *h, const float *eps_ring, int32_t n_slots);
 /* iteration counter that keys the sampler (checkpoint / resume) */
 int mppi_set_iteration(mppi_handle *h, int64_t iteration);
 
@@ -341,6 +359,12 @@ int mppi_time_rollout_launch(mppi_handle *h, int32_t n_slots, int32_t extra, voi
  * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128);
  * +4 = every (half-)wave rolls out two samples in sequence.  -1: the handle does not use the fused kernels. */
 int mppi_get_rollout_layout(const mppi_handle *h, int32_t *layout);
+/* The kernel instantiation the handle's last rollout-class launch took, spelled as rocprofv3 prints it (e.g.
+ * "k_rollout_fused<float, 0, 1, false, 2, false>", "k_rollout_dual<float, 1, 1, false, 2, true>"): bench.py looks the
+ * launch's counter figures up under this name in profiles/.  A learned-dynamics handle answers as soon as mppi_set_mlp has
+ * run: "k_rollout_mlp_h3<false>" (operands as two f16 halves, the default) or "k_rollout_mlp(" (f32-input MFMA: chosen by
+ * MPPI_MLP_F32=1, or by mppi_set_mlp itself when a weight exceeds the f16 range). */
+int mppi_get_rollout_kernel(const mppi_handle *h, char *buf, int32_t n);
 
 /*
  * `pytorch_mppi`-style MPPI with built-in dynamics / running-cost models: the callbacks the

@@ -1,6 +1,8 @@
 """GPU: engine-level checks at BASELINE sizes -- sampler vs its NumPy restatement, the full-size
 config against the C oracle, and size-independent properties (shard invariance, softmin shift
 invariance, permutation invariance of the weighted reduce)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -252,6 +254,35 @@ def test_peer_exchange_three_shards_in_one_process():
         np.testing.assert_allclose(e.get_u_prev(), whole.get_u_prev(), rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(e.get_state(), whole.get_state(), rtol=1e-9, atol=1e-12)
         e.comm_close()
+
+
+def test_peer_connect_refuses_a_local_peer_it_cannot_reach():
+    """`local_ptrs` entries are used as they are, so mppi_comm_connect checks them: a pointer that is not device memory
+    (here: pinned host memory and a plain host address) is refused with MPPI_ERR_UNSUPPORTED instead of being stored
+    into by the finalize kernel; a peer on another GPU gets peer access enabled (or the same refusal) -- one GPU here."""
+    import ctypes
+
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    e = pkg.Engine(model=capi.MODEL_RACECAR, K=256, K_global=512, k_offset=0, T=20, delta_t=0.05, u_max=[0.523, 2.0],
+                   wheel_base=2.5, param_exploration=0.1, param_lambda=50.0, param_alpha=0.9, sigma=[0.5, 0.0, 0.0, 0.1],
+                   stage_cost_weight=[50.0, 50.0, 1.0, 20.0], terminal_cost_weight=[50.0, 50.0, 1.0, 20.0],
+                   beta_mode=capi.BETA_INV_LAMBDA, accumulate_stage_cost=1, waypoint_mode=capi.WAYPOINT_FROZEN,
+                   search_window=200, filter_mode=capi.FILTER_RACECAR, filter_window=10, seed=1)
+    e.set_ref_path(lem)
+    handles = [e.comm_export(2), b"\0" * e.lib.mppi_comm_handle_bytes()]
+    pinned = torch.empty(4096, dtype=torch.uint8).pin_memory()
+    plain = ctypes.create_string_buffer(4096)
+    for bad in (pinned.data_ptr(), ctypes.addressof(plain)):
+        with pytest.raises(pkg.MppiError) as ei:
+            e.comm_connect(0, handles, local_ptrs=[None, bad])
+        assert ei.value.code == capi.ERR_UNSUPPORTED, ei.value
+    dev = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")  # device memory of the handle's own GPU: accepted
+    e.comm_connect(0, handles, local_ptrs=[None, dev.data_ptr()])
+    e.comm_close()
 
 
 def test_peer_exchange_missing_rank_times_out(monkeypatch):
@@ -862,3 +893,123 @@ def test_racecar_closed_loop_does_not_depend_on_how_it_is_chunked():
     np.testing.assert_array_equal(np.concatenate(tr_p), tr_w)
     np.testing.assert_array_equal(parts._engine.get_state(), whole._engine.get_state())
     assert st_p.idx_after == st_w.idx_after and st_w.idx_after > 0
+
+
+@pytest.mark.parametrize("case", ["fused", "dual", "race", "batched"])
+def test_closed_loop_from_a_noise_ring_equals_the_sampler(case):
+    """`mppi_set_noise_ring`: `_calc_epsilon` materialised for the device closed loop (mppi_differential_drive.py:273-283).
+    A ring filled with the sampler's own tensors of iterations 0..n-1 must give the run the in-kernel sampler gives --
+    the rollout reads its noise from HBM instead of drawing it (general instantiations instead of the PLAIN ones: last-bit
+    differences in f32), the slot is picked inside the kernels from the device's iteration counter, and the ring wraps."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    n_slots, n_it = 4, 7  # (wraps: iterations 4..6 reuse slots 0..2, so the reference run below rewinds its counter)
+    if case == "race":
+        ref = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+        base = dict(model=capi.MODEL_RACECAR, K=1000, T=75, delta_t=0.05, u_max=[0.523, 2.0], wheel_base=2.5,
+                    param_exploration=0.1, param_lambda=50.0, param_alpha=0.9, sigma=[0.5, 0.0, 0.0, 0.1],
+                    stage_cost_weight=[50.0, 50.0, 1.0, 20.0], terminal_cost_weight=[50.0, 50.0, 1.0, 20.0],
+                    beta_mode=capi.BETA_INV_LAMBDA, accumulate_stage_cost=1, waypoint_mode=capi.WAYPOINT_FROZEN,
+                    search_window=200, wrap_yaw_stage=1, wrap_yaw_terminal=1, clamp_rollout=1, clamp_u_after_update=1,
+                    filter_mode=capi.FILTER_RACECAR, filter_window=10, obstacle_model=capi.OBSTACLE_OUTLINE, safety_margin=1.5,
+                    vehicle_w=3.0, vehicle_l=4.0, collision_penalty=1e10, seed=7, precision=capi.PREC_F64)
+        x0 = ref[2].astype(np.float64)
+    else:
+        ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100)
+        base = dict(model=capi.MODEL_DIFFDRIVE, K=9000 if case == "dual" else 700, T=50, delta_t=0.1, u_max=[5.0, 3.14],
+                    param_exploration=0.05, param_lambda=1.0, param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01],
+                    stage_cost_weight=[5, 5, 10, 0], terminal_cost_weight=[5, 5, 10, 0], search_window=20, filter_window=10,
+                    clamp_rollout=1, waypoint_mode=capi.WAYPOINT_FROZEN if case == "batched" else capi.WAYPOINT_SEQUENTIAL,
+                    seed=99, precision=capi.PREC_F64)
+        x0 = np.array([0.1, -0.05, 0.2])
+        if case == "batched":
+            base["n_agents"] = 3
+            x0 = np.stack([x0 + 0.1 * a for a in range(3)])
+
+    def make():
+        e = pkg.Engine(**base)
+        e.set_ref_path(ref)
+        if case == "race":
+            e.set_obstacles(np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]))
+        e.set_state(x0)
+        return e
+    a, b = make(), make()
+    ring = torch.stack([b.sample_epsilon(i) for i in range(n_slots)])
+    assert tuple(ring.shape[1:]) == b._lead + (b.K, b.T, 2)
+    b.set_noise_ring(ring)
+    b.run_closed_loop(n_it)
+    a.run_closed_loop(n_slots)       # the sampler's run over iterations 0..3, then 0..2 again
+    a.set_iteration(0)
+    a.run_closed_loop(n_it - n_slots)
+    b_iter = b.counters()["iterations"]
+    assert b_iter == n_it
+    np.testing.assert_allclose(b.get_u_prev(), a.get_u_prev(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b.get_state(), a.get_state(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b.costs(), a.costs(), rtol=1e-9, atol=1e-9)
+    b.set_noise_ring(None)  # back to the sampler: the handle continues with the draw of its iteration counter
+    a.set_iteration(n_it)
+    a.run_closed_loop(2)
+    b.run_closed_loop(2)
+    np.testing.assert_allclose(b.get_u_prev(), a.get_u_prev(), rtol=1e-9, atol=1e-12)
+    with pytest.raises(pkg.MppiError):  # three slots: not a power of two
+        b.set_noise_ring(ring[:3].contiguous())
+
+
+def test_rollout_kernel_name_follows_the_layout():
+    """`mppi_get_rollout_kernel`: the instantiation the last rollout launch took, as rocprofv3 spells it (bench.py looks the
+    launch's counters up by it)."""
+    import dnn_mppi_mpc_amd as pkg
+    c = pkg.MPPIAlgorithms(**dd_kwargs(4096, 50), precision="f32", seed=1)
+    c._engine.set_state(np.zeros(3))
+    c._engine.run_closed_loop(2)
+    assert c._engine.rollout_kernel() == "k_rollout_fused<float, 0, 1, false, 2, true>"  # the index can still move
+    c._engine.run_closed_loop(60)
+    c._engine.run_closed_loop(2)
+    assert c._engine.rollout_kernel() == "k_rollout_fused<float, 0, 1, false, 2, false>"  # at the end of the path: lean
+    d = pkg.MPPIAlgorithms(**dd_kwargs(16384, 50), precision="f32", seed=1, waypoint_mode="frozen")
+    d._engine.set_state(np.zeros(3))
+    d._engine.run_closed_loop(1)
+    assert d._engine.rollout_kernel().startswith("k_rollout_dual<float, 0, 2, false, ")
+
+
+def test_learned_dynamics_outside_the_f16_range():
+    """The default learned-dynamics kernel carries operands as pairs of f16 numbers.  (i) A path in UTM-sized coordinates
+    (1e5 m, no scalers): raw inputs and first-layer pre-activations beyond 65504 are handled by per-sample power-of-two
+    scales inside the kernel -- costs finite and equal to the f32-input MFMA kernel's to the split's accuracy; (ii) a WEIGHT
+    beyond the range (a StandardScaler scale of 1e-6 folded into the first Linear) cannot be split: mppi_set_mlp selects
+    the f32-input kernel for that model and says so."""
+    import dnn_mppi_mpc_amd as pkg
+    rng = np.random.default_rng(11)
+    w = {"input_layer.weight": rng.normal(0, 0.3, (512, 5)), "input_layer.bias": rng.normal(0, 0.1, 512),
+         "out_layer.weight": rng.normal(0, 0.05, (3, 512)), "out_layer.bias": rng.normal(0, 0.01, 3)}
+    for i in range(3):
+        w[f"hidden_layer.{i}.weight"] = rng.normal(0, 0.04, (512, 512))
+        w[f"hidden_layer.{i}.bias"] = rng.normal(0, 0.1, 512)
+    off = np.array([4.0e5, 5.5e6, 0.0])  # (UTM easting / northing)
+    path = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100) + off
+    kw = dd_kwargs(512, 20, ref_path=path)
+    x0 = np.array([0.3, -0.1, -0.4]) + off
+    runs = {}
+    for kernel in ("f16x3", "f32"):
+        if kernel == "f32":
+            os.environ["MPPI_MLP_F32"] = "1"
+        try:
+            c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode="frozen", seed=3)
+        finally:
+            os.environ.pop("MPPI_MLP_F32", None)
+        assert c._engine.rollout_kernel() == ("k_rollout_mlp(" if kernel == "f32" else "k_rollout_mlp_h3<false>")
+        u = c._calc_input_control(x0)[1].copy()
+        runs[kernel] = (u, c.sample_costs().copy())
+    (u_h, S_h), (u_f, S_f) = runs["f16x3"], runs["f32"]
+    assert np.isfinite(S_h).all() and np.isfinite(u_h).all()
+    # at 5e6 m an f32 position resolves 0.5 m: the two kernels agree to that arithmetic, not to centimetres
+    np.testing.assert_allclose(S_h, S_f, rtol=2e-3)
+    assert rmse(u_h, u_f) <= 1e-3
+    # (ii) a weight beyond the f16 range
+    scalers = dict(in_mean=np.zeros(5), in_scale=np.array([1e-6, 1.0, 1.0, 1.0, 1.0]), out_mean=np.zeros(3), out_scale=np.ones(3))
+    c = pkg.MPPIAlgorithms(**dd_kwargs(256, 20), learned_dynamics=w, learned_scalers=scalers, waypoint_mode="frozen", seed=3)
+    assert c._engine.rollout_kernel() == "k_rollout_mlp("
+    c._calc_input_control(np.array([1e-7, 0.0, 0.0]))
+    assert np.isfinite(c.sample_costs()).all()
