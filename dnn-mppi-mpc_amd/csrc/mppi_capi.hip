@@ -9,6 +9,7 @@
 
 #include <time.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -220,7 +221,7 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->graph_on = getenv("MPPI_GRAPH") && atoi(getenv("MPPI_GRAPH")) != 0;  // (opt-in: see ensure_graph)
     h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64);
     h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
-    if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K);
+    if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K, 64);  // (mppi_set_mlp sets it again for the kernel that serves the model)
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
     auto fail = [&](hipError_t e, const char *what) {
         g_create_error = std::string(what) + " failed: " + hipGetErrorString(e);
@@ -237,7 +238,10 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc((void **)&h->d_pout, B * sizeof(int) * c.K)) != hipSuccess) return fail(e, "hipMalloc(pout)");
     const size_t rec_bytes = sizeof(double) * (size_t)record_len(c.T, 8);  // enough for either precision
     // zero-filled and padded by 256 records: the merge kernels read 256 slots unconditionally
-    const size_t slots = (size_t)h->n_part + 256, n1 = B * slots, n2 = (size_t)h->n_part / 64 + 2 + 256;
+    // (the streaming kernel that serves noise tensors in the two-samples-per-wave layout leaves up to one record per 32
+    // samples whatever the handle's own count is: room for the larger of the two)
+    const size_t n_rec_max = std::max<size_t>((size_t)h->n_part, (h->layout & LAYOUT_KIND) == LAYOUT_DUAL ? ((size_t)c.K + 31) / 32 : 0);
+    const size_t slots = n_rec_max + 256, n1 = B * slots, n2 = n_rec_max / 64 + 2 + 256;
     h->slots = (int)slots;
     if ((e = hipMalloc(&h->d_partials, rec_bytes * n1)) != hipSuccess) return fail(e, "hipMalloc(partials)");
     if ((e = hipMalloc(&h->d_partials2, rec_bytes * n2)) != hipSuccess) return fail(e, "hipMalloc(partials2)");
@@ -426,6 +430,7 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
         h->mlp.in_gain = (float)(gain * (1.0 + 1e-6));
         h->mlp.in_bias = (float)(bias * (1.0 + 1e-6));
     }
+    h->n_part = mlp_blocks(h->cfg.K, mlp_tile(h->mlp));  // records the rollout kernel that serves this model leaves
     h->mlp_set = true;
     return MPPI_OK;
 }
@@ -710,15 +715,17 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
     if (!mlp && !h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
+    // (records per agent this launch left: the handle's count, or fewer when the streaming kernel served a noise tensor)
+    const int n_part = (!mlp && h->fused) ? fused_records<R>(P) : h->n_part;
     *recs = h->d_partials;
     *heads = h->d_heads;
-    *n_recs = h->n_part;
-    if (h->n_part > MAX_DIRECT_PARTS) {
-        const int group = h->n_part > 64 * MAX_FINAL_PARTS ? MAX_FINAL_PARTS : 64;
-        launch_merge<R>(h->d_partials, h->d_heads, h->n_part, group, h->cfg.T, beta, h->d_partials2, h->d_heads2, false, s);
+    *n_recs = n_part;
+    if (n_part > MAX_DIRECT_PARTS) {
+        const int group = n_part > 64 * MAX_FINAL_PARTS ? MAX_FINAL_PARTS : 64;
+        launch_merge<R>(h->d_partials, h->d_heads, n_part, group, h->cfg.T, beta, h->d_partials2, h->d_heads2, false, s);
         *recs = h->d_partials2;
         *heads = h->d_heads2;
-        *n_recs = (h->n_part + group - 1) / group;
+        *n_recs = (n_part + group - 1) / group;
     }
     if (tm) hipEventRecord(next_event(h), s);
 }

@@ -191,6 +191,8 @@ const char *last_rollout_kernel();
 enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
 int rollout_layout(int K, int T, int n_agents, int model, bool f64);  // n_agents: problems batched in one launch
 int fused_blocks(int K, int T, int layout);  // workgroups = block records of one launch
+// records launch_rollout_fused(P) leaves (the streaming kernel, which serves tensors of noise, leaves fewer: see k_rollout_stream)
+template <typename R> int fused_records(const KParams<R> &P);
 // merges groups of `group` <= 256 records (precision R) of `recs[n]` into out[ceil(n/group)]
 // (`heads` / `out_heads`: the compact head arrays of the input / internal-layout output records)
 template <typename R>
@@ -229,7 +231,8 @@ void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *parti
 void launch_eval_mlp(const KParams<float> &P, const MlpParams &Q, const float *x, const float *v, int n, float *out, hipStream_t s);
 void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
                     float *opt, float *smp, hipStream_t s);
-int mlp_blocks(int K);
+int mlp_blocks(int K, int tile);            // workgroups = softmin records of a launch over K samples
+int mlp_tile(const MlpParams &Q);          // samples per workgroup of the rollout kernel that serves Q (32 or 64)
 const char *mlp_kernel_name(const MlpParams &Q);  // as rocprofv3 spells the rollout kernel that serves Q
 void pack_linear(const float *w, int n_in, float *packed);  // host: [512][n_in] -> fragment order
 void pack_linear_h3(const float *w, int n_in, unsigned short *packed);  // host: -> two f16 planes in fragment order

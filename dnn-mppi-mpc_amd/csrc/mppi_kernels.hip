@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -951,6 +952,185 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
         if (seq_search) publish_first_mover<ROWS>(sh_mover, &(P.st + agent)->first_k);
     }
     STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------
+// The memory-bound form of the analytic path (north star: "coalesced HBM loads of the [K,T,nu] noise tensor"): the noise
+// of `_calc_epsilon` (mppi_differential_drive.py:273-283) arrives as a tensor in HBM -- the caller's, or a slot of the
+// noise ring (mppi_set_noise_ring) -- instead of being drawn in registers.  Read by the general kernels above, one
+// workgroup per 32 samples, the launch is SLOWER than drawing the noise (32 batched config-2 agents: 61 against 41 us):
+// every wave issues one load, waits an HBM round trip for it, computes, and leaves; nothing is in flight meanwhile.
+// Here a workgroup STREAMS: it owns `n_pass` consecutive batches of 32 samples and requests batch i+1's rows (16 bytes per
+// lane: the two steps a lane owns, eps[k, 2l .. 2l+1, :]) before it rolls out batch i, so the HBM latency is spent under
+// arithmetic; a half-wave's 25 lanes read 400 contiguous bytes, a workgroup 12.8 KB per batch.  With the grid sized to
+// two workgroups per CU (64 VGPRs), every CU keeps 25 KB of noise in flight throughout the launch.
+//
+// Diff-drive, two samples per wave / two steps per lane (T <= 64), frozen waypoint index, `S[k] =` (:124) -- the batched
+// and large-K forms the memory roof matters for.  No workgroup barrier inside the loop: every half-wave merges ITS samples
+// online into a private softmin record -- after a sample with cost S: rho <- min(rho, S), what is accumulated so far is
+// rescaled by exp(-beta (rho_old - rho)) and the sample enters with e = exp(-beta (S - rho)) (:175); the lane that owns
+// steps 2l, 2l+1 keeps the four sums W[2l .. 2l+1][0..1] (:132-135) in registers -- so the waves of a workgroup drift
+// apart and cover each other's waits; the 32 private records meet once, at the end, in LDS, and the workgroup leaves ONE
+// record for all its batches (k_finalize merges n_pass times fewer).
+// The frozen index makes every cost call of a sample search the SAME window [c, c + wlen) and `S[k] =` keeps only the
+// last step's: one search per sample, its <= 32 candidates spread over the lanes of the half-wave.
+// ------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: `__syncthreads()` also waits for every outstanding vector-memory access
+// (s_waitcnt vmcnt(0))
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename R, bool MULTI, bool OBS>
+__global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rollout_stream(const DevState *st_pre, const KParams<R> P,
+                                                                                            R *__restrict__ partials, int n_pass) {
+    constexpr int ROWS = DUAL_SAMPLES;  // half-waves of the workgroup = samples in flight
+    const int agent = MULTI ? (int)blockIdx.y : 0;
+    const R *__restrict__ u_ = P.u + (size_t)agent * 2 * P.T;
+    R *__restrict__ S_ = P.S + (size_t)agent * P.K;
+    __shared__ R sh_rho[ROWS];
+    __shared__ R sh_eta[ROWS][2];
+    __shared__ __attribute__((aligned(16))) R sh_acc[ROWS][128];
+    __shared__ __attribute__((aligned(16))) float sh_raw[ROWS][128];
+    __shared__ __attribute__((aligned(16))) R sh_u[128];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l32 = lane & 31;
+    const int sidx = wid * 2 + h;
+    const DevState sv = load_state(P, st_pre + agent);
+    const int c = sv.c, T = P.T, K = P.K, t0 = 2 * l32, t1 = t0 + 1;
+    const bool a0 = t0 < T, a1 = t1 < T;
+    const int n_batch = (K + ROWS - 1) / ROWS, b0 = (int)blockIdx.x * n_pass;
+    const float *__restrict__ eps = eps_tensor(P, (unsigned)sv.iter, agent);
+    // Unconditional loads from clamped addresses (what lies beyond the horizon or the last sample is masked where it is
+    // used): a load under a per-lane condition makes the compiler wait for it at the end of the branch, i.e. right away.
+    // Two 8-byte loads per lane (a row of odd length leaves its second half 8-byte aligned only).
+    const float *__restrict__ row0 = eps + (size_t)(t0 < T ? t0 : T - 1) * 2, *__restrict__ row1 = eps + (size_t)(t1 < T ? t1 : T - 1) * 2;
+    auto request = [&](int batch, float4 &e) {
+        int k = batch * ROWS + sidx;
+        k = k < K ? k : K - 1;
+        const size_t off = (size_t)k * T * 2;
+        const float2 ea = *reinterpret_cast<const float2 *>(row0 + off), eb = *reinterpret_cast<const float2 *>(row1 + off);
+        e = make_float4(ea.x, ea.y, eb.x, eb.y);
+    };
+    float4 e_next;
+    request(b0, e_next);  // the first batch's rows fly while the prologue below runs
+    const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
+    const int wlen = window_len<R>(P.window, P.n_ref, c);
+    // the frozen window's candidates, one per lane of each half-wave (the host sends windows of up to 32 candidates here)
+    R cand_x = R(0), cand_y = R(0), cand_yaw = R(0);
+    if (l32 < wlen) { cand_x = P.ref[4 * (c + l32)]; cand_y = P.ref[4 * (c + l32) + 1]; cand_yaw = P.ref[4 * (c + l32) + 2]; }
+    if (tid < 128) sh_u[tid] = tid < 2 * T ? u_[tid] : R(0);  // u[t][channel]: the same for every batch
+    __syncthreads();
+    const R x_0 = (R)sv.x0[0], y_0 = (R)sv.x0[1], yaw_0 = (R)sv.x0[2];
+    const int t_last = T - 1, lane_last = t_last >> 1, sub_last = t_last & 1;
+    // the control cost of the last step, u^T Sigma^-1 v (:124), as two wave-uniform coefficients of v
+    const R u_la = sh_u[2 * t_last], u_lb = sh_u[2 * t_last + 1];
+    const R ca = wv::read_lane(u_la * P.sinv[0] + u_lb * P.sinv[2], 0), cb = wv::read_lane(u_la * P.sinv[1] + u_lb * P.sinv[3], 0);
+    // this half-wave's private record (rho, eta, eta2 uniform within the half; w*: this lane's four columns)
+    R rho_h = R(INFINITY), eta_h = R(0), eta2_h = R(0), w0 = R(0), w1 = R(0), w2 = R(0), w3 = R(0);
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int batch = b0 + pass;
+        if (batch >= n_batch) break;  // (uniform over the workgroup)
+        const int k = batch * ROWS + sidx;
+        const bool valid = k < K;
+        const bool exploit = (k + P.k_offset) < P.n_exploit;
+        R v00, v01, v10, v11;
+        {   // (the noise waits in this lane's own LDS slot until the sample's weight is known; the nominal controls come from
+            // LDS per batch: eight registers fewer across the arithmetic below, which keeps the kernel at 64 VGPRs)
+            const float4 e = e_next;
+            request(batch + 1, e_next);  // (past the last batch: a clamped re-read, cheaper than a branch around the loads)
+            *reinterpret_cast<float4 *>(&sh_raw[sidx][4 * l32]) = e;
+            const VecT4<R> uu = *reinterpret_cast<const VecT4<R> *>(&sh_u[4 * l32]);  // u<step><channel>
+            v00 = exploit ? uu.x + (R)e.x : (R)e.x; v01 = exploit ? uu.y + (R)e.y : (R)e.y;  // :116-119
+            v10 = exploit ? uu.z + (R)e.z : (R)e.z; v11 = exploit ? uu.w + (R)e.w : (R)e.w;
+        }
+        if (P.clamp_rollout) {  // `_g` :285-289
+            v00 = mf::clamp(v00, P.umax0); v01 = mf::clamp(v01, P.umax1);
+            v10 = mf::clamp(v10, P.umax0); v11 = mf::clamp(v11, P.umax1);
+        }
+        if (!a0) { v00 = 0; v01 = 0; }
+        if (!a1) { v10 = 0; v11 = 0; }
+        // dynamics (:194-196), exactly as k_rollout_dual<.., MODEL_DIFF, 2, ..> associates them
+        const R d0 = v01 * P.dt, d1 = v11 * P.dt;
+        const R yb0 = yaw_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(d0 + d1), R(0));
+        const R yw0 = yb0 + d0, yw1 = yw0 + d1;
+        R s0, c0, s1, c1;
+        mf::sincos_(yb0, s0, c0);
+        mf::sincos_(yw0, s1, c1);
+        const R dx0 = v00 * c0 * P.dt, dx1 = v10 * c1 * P.dt, dy0 = v00 * s0 * P.dt, dy1 = v10 * s1 * P.dt;
+        const R px0 = x_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dx0 + dx1), R(0)) + dx0, px1 = px0 + dx1;
+        const R py0 = y_0 + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(dy0 + dy1), R(0)) + dy0, py1 = py0 + dy1;
+        // the state after the last step, held by lane_last of each half; broadcast within the half
+        const R lx_l = sub_last ? px1 : px0, ly_l = sub_last ? py1 : py0, lyaw_l = sub_last ? yw1 : yw0;
+        const R lx = h ? wv::read_lane(lx_l, 32 + lane_last) : wv::read_lane(lx_l, lane_last);
+        const R ly = h ? wv::read_lane(ly_l, 32 + lane_last) : wv::read_lane(ly_l, lane_last);
+        const R lyaw = h ? wv::read_lane(lyaw_l, 32 + lane_last) : wv::read_lane(lyaw_l, lane_last);
+        // the one search this sample's cost needs (`_get_nearest_waypoint`, :201-220: first minimum over [c, c + wlen))
+        // (the waypoint the cost is taken against comes out of the candidate registers: a load from the path here would
+        // make the wave wait for the batch requested above as well -- vector-memory loads return in order)
+        R wx, wy, wyaw;
+        {
+            const R ddx = lx - cand_x, ddy = ly - cand_y;
+            const R d = l32 < wlen ? ddx * ddx + ddy * ddy : R(INFINITY);
+            const R ms = wv::scan_incl_half<wv::OpMin>(d);
+            const R m = h ? wv::read_lane(ms, 63) : wv::read_lane(ms, 31);
+            const int js = wv::scan_incl_half<wv::OpMinInt>(d == m ? l32 : 0x7fffffff);
+            const int ja = wv::read_lane(js, 31), jb = wv::read_lane(js, 63);
+            wx = h ? wv::read_lane(cand_x, jb) : wv::read_lane(cand_x, ja);
+            wy = h ? wv::read_lane(cand_y, jb) : wv::read_lane(cand_y, ja);
+            wyaw = h ? wv::read_lane(cand_yaw, jb) : wv::read_lane(cand_yaw, ja);
+        }
+        // costs (`S[k] =`: the last step's stage cost + the terminal cost of the same state, :124,:128; `_compute_cost`
+        // :222-236 as tracking_cost<.., MODEL_DIFF> writes it)
+        auto track = [&](const R (&w)[4], bool wrap) {
+            const R yw = wrap ? mf::pymod(lyaw + P.two_pi, P.two_pi) : lyaw;
+            const R ex = lx - wx, ey = ly - wy, eyaw = yw - wyaw;
+            return w[0] * (ex * ex) + w[1] * (ey * ey) + w[2] * (eyaw * eyaw);
+        };
+        const bool hit = OBS ? collided<false>(P, lx, ly, lyaw, obs) : false;
+        R st_c = track(P.ws, P.wrap_stage);
+        if (hit) st_c += P.penalty;
+        const R va = sub_last ? v10 : v00, vb = sub_last ? v11 : v01;
+        const R ctrl_l = ca * va + cb * vb;
+        const R ctrl = h ? wv::read_lane(ctrl_l, 32 + lane_last) : wv::read_lane(ctrl_l, lane_last);
+        R term = track(P.wt, P.wrap_term);
+        if (hit) term += P.penalty;
+        const R S_k = (st_c + P.gamma * ctrl) + term;
+        if (l32 == 0 && valid) S_[k] = S_k;
+        if (valid) {  // (uniform within the half) merge the sample into the half-wave's record
+            const R rho_new = fmin(rho_h, S_k);
+            const R scale = rho_h < R(INFINITY) ? mf::exp_(-P.beta * (rho_h - rho_new)) : R(0);
+            const R e_w = mf::exp_(-P.beta * (S_k - rho_new));  // :175
+            const float4 e = *reinterpret_cast<const float4 *>(&sh_raw[sidx][4 * l32]);  // (own slot: no barrier needed)
+            w0 = w0 * scale + e_w * (R)e.x; w1 = w1 * scale + e_w * (R)e.y;  // :132-135
+            w2 = w2 * scale + e_w * (R)e.z; w3 = w3 * scale + e_w * (R)e.w;
+            eta_h = eta_h * scale + e_w;
+            eta2_h = eta2_h * scale * scale + e_w * e_w;
+            rho_h = rho_new;
+        }
+    }
+    // the 32 private records -> the workgroup's record
+    if (l32 == 0) sh_rho[sidx] = rho_h;
+    __syncthreads();
+    const R rho = wv::read_lane(wv::scan_incl_half<wv::OpMin>(sh_rho[l32]), 31);
+    const R sc = rho_h < R(INFINITY) ? mf::exp_(-P.beta * (rho_h - rho)) : R(0);
+    if (l32 == 0) { sh_eta[sidx][0] = sc * eta_h; sh_eta[sidx][1] = sc * sc * eta2_h; }
+    *reinterpret_cast<VecT4<R> *>(&sh_acc[sidx][4 * l32]) = VecT4<R>{sc * w0, sc * w1, sc * w2, sc * w3};
+    __syncthreads();
+    const size_t slot = (size_t)agent * P.slots + blockIdx.x;  // this workgroup's record
+    R *out = partials + slot * record_len(T, (int)sizeof(R));
+    if (tid < 2 * T) {
+        R acc = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) acc += sh_acc[q][tid];
+        out[4 + tid] = acc;
+    }
+    if (tid == 64 * (DUAL_WAVES - 1)) {
+        R eta = 0, eta2 = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) { eta += sh_eta[q][0]; eta2 += sh_eta[q][1]; }
+        out[0] = rho;
+        out[1] = eta;
+        out[2] = eta2;
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2059,7 +2239,41 @@ int fused_blocks(int K, int T, int layout) {
     return (K + per_block - 1) / per_block;
 }
 
+// The streaming kernel serves: noise from a tensor, diff-drive, the two-samples-per-wave layout, frozen index, `S[k] =`.
+// Batches of 32 samples per workgroup: as many as leave about 1024 workgroups (two rounds of two per CU), at most 16.
+template <typename R> static int stream_passes(const KParams<R> &P) {
+    if (P.eps == nullptr || P.model != MODEL_DIFF || P.sequential || P.accumulate || P.T > 64 || P.window > 32 ||
+        (P.layout & LAYOUT_KIND) != LAYOUT_DUAL)
+        return 0;
+    static const bool off = getenv("MPPI_NO_STREAM") != nullptr;  // (A/B runs)
+    if (off) return 0;
+    const long long batches = (long long)((P.K + DUAL_SAMPLES - 1) / DUAL_SAMPLES) * (P.n_agents > 1 ? P.n_agents : 1);
+    static const int forced = getenv("MPPI_STREAM_PASSES") ? atoi(getenv("MPPI_STREAM_PASSES")) : 0;  // (experiments)
+    if (forced > 0) return forced;
+    int np = (int)(batches / 1024);  // (measured, 32 agents of K = 4096: 2 / 4 / 8 / 16 batches -> 32.8 / 30.8 / 31.3 / 35.6 us)
+    return np < 1 ? 1 : np > 16 ? 16 : np;
+}
+template <typename R> int fused_records(const KParams<R> &P) {
+    const int np = stream_passes(P);
+    if (np == 0) return fused_blocks(P.K, P.T, P.layout);
+    const int batches = (P.K + DUAL_SAMPLES - 1) / DUAL_SAMPLES;
+    return (batches + np - 1) / np;
+}
+template int fused_records<float>(const KParams<float> &);
+template int fused_records<double>(const KParams<double> &);
+
 template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const KParams<R> &P, R *partials, hipStream_t s) {
+    if (const int np = stream_passes(P)) {
+        const dim3 sgrid(fused_records(P), MULTI ? P.n_agents : 1);
+        if (P.obstacle_model != OBS_NONE) {
+            MPPI_NOTE_KERNEL("k_rollout_stream<%s, %s, true>", type_name<R>(), tf(MULTI));
+            hipLaunchKernelGGL((k_rollout_stream<R, MULTI, true>), sgrid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials, np);
+        } else {
+            MPPI_NOTE_KERNEL("k_rollout_stream<%s, %s, false>", type_name<R>(), tf(MULTI));
+            hipLaunchKernelGGL((k_rollout_stream<R, MULTI, false>), sgrid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials, np);
+        }
+        return;
+    }
     const dim3 grid(fused_blocks(P.K, P.T, P.layout), MULTI ? P.n_agents : 1);
     const bool twice = (P.layout & LAYOUT_TWICE) != 0;
     const bool race = MODEL == MODEL_RACE;

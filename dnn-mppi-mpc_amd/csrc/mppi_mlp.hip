@@ -16,6 +16,7 @@
 // groups).  Per k-group: 2 LDS reads + 4 global loads feed 32 MFMAs (2048 cycles), so the loop is
 // MFMA-bound; the next group's operands are loaded before the current group's MFMAs issue.
 // 1 581 056 flop per trajectory-step.
+#include <stdlib.h>
 #include <string.h>
 
 #include "mppi_device.h"
@@ -30,12 +31,13 @@ struct alignas(16) F4 { float v[4]; };
 // Wave 0 searches the nearest waypoint of 64 samples every step while the other waves wait for it: the path (x, y, yaw, v
 // per waypoint) is copied to LDS once per launch when it fits the 16 KB left beside the activations, so the search reads
 // LDS instead of walking global memory (20 dependent loads per call, 5 % of the launch).
-constexpr int MLP_REF_LDS_MAX = 1024;
+constexpr int MLP_REF_LDS_MAX = 768;  // (12 KB: what the 8-wave form of the f16-split kernel leaves beside its buffers)
 
 // the path in LDS (returns the parameter block the per-sample code should use)
-__device__ __forceinline__ KParams<float> mlp_stage_path(const KParams<float> &P, float *ref_lds) {
+constexpr int H3_REF_LDS_32 = 256;  // the same beside a 32-sample tile (two workgroups share the CU's LDS)
+__device__ __forceinline__ KParams<float> mlp_stage_path(const KParams<float> &P, float *ref_lds, int cap = MLP_REF_LDS_MAX) {
     KParams<float> PL = P;
-    if (P.n_ref <= MLP_REF_LDS_MAX) {
+    if (P.n_ref <= cap) {
         for (int i = threadIdx.x; i < P.n_ref; i += blockDim.x)
             reinterpret_cast<F4 *>(ref_lds)[i] = reinterpret_cast<const F4 *>(P.ref)[i];
         PL.ref = ref_lds;  // (first read behind the first workgroup barrier of the step loop)
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
 // ------------------------------------------------------------------------------------------
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int H3_PITCH = 520, H3_ZPITCH = 24, H3_STEPS = MLP_H / 16;
+constexpr int H3_FORM_DEFAULT = 1;  // (H3_FORM_8x64, see h3_form)
 
 __device__ __forceinline__ void split_h3(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
@@ -401,9 +404,12 @@ struct H3Ring { H3FragB b0, b1, b2; };  // k-steps 0, 1, 2 of the pass about to 
 
 // this lane's view of the two column tiles of (layer `w`, pass): + (c2 * n_steps + s) * 64
 struct H3Pass { const half8 *hi, *lo; };
-__device__ __forceinline__ H3Pass h3_pass(const unsigned short *layer, int n_steps, int wid, int pass, int lane) {
+// NW waves per workgroup (4: one per SIMD, each owns 128 output columns = two passes of two column tiles; 8: two per SIMD,
+// each owns 64 columns = one pass -- the same MFMAs, weight bytes and LDS reads per SIMD, but the two waves of a SIMD cover
+// each other's waits in the GEMMs and share the VALU in the epilogues, which a single wave issues at half the pipe's rate)
+template <int NW> __device__ __forceinline__ H3Pass h3_pass(const unsigned short *layer, int n_steps, int wid, int pass, int lane) {
     const half8 *w = reinterpret_cast<const half8 *>(layer);
-    const size_t off = (size_t)(wid * 4 + 2 * pass) * n_steps * 64 + lane;
+    const size_t off = (size_t)(wid * (16 / NW) + 2 * pass) * n_steps * 64 + lane;
     return H3Pass{w + off, w + (size_t)16 * n_steps * 64 + off};
 }
 __device__ __forceinline__ void h3_load_b(const H3Pass &w, int n_steps, int s, H3FragB &f) {
@@ -419,23 +425,24 @@ __device__ __forceinline__ void h3_prime(const H3Pass &w, int n_steps, H3Ring &r
     h3_load_b(w, n_steps, 2, r.b2);
 }
 // (the three terms as three sweeps over the four tiles: independent accumulators between two MFMAs on the same one)
-__device__ __forceinline__ void h3_mma(f32x16 (&ac)[2][2], const H3FragA &a, const H3FragB &b) {
+// RT = row tiles of 32 samples a workgroup owns (2: the 64-sample tile; 1: a 32-sample tile, two workgroups per CU)
+template <int RT> __device__ __forceinline__ void h3_mma(f32x16 (&ac)[RT][2], const H3FragA &a, const H3FragB &b) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.l[rt], ac[rt][c2], 0, 0, 0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) ac[rt][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[c2], a.h[rt], ac[rt][c2], 0, 0, 0);
 }
-__device__ __forceinline__ void h3_zero(f32x16 (&ac)[2][2]) {
+template <int RT> __device__ __forceinline__ void h3_zero(f32x16 (&ac)[RT][2]) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -444,14 +451,14 @@ __device__ __forceinline__ void h3_zero(f32x16 (&ac)[2][2]) {
 
 // one pass (two column tiles) of a 512-wide hidden layer: `ring` holds its k-steps 0..2 on entry and (HAS_NEXT) those of
 // `next` on exit
-template <bool HAS_NEXT>
-__device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 *a_hi, const _Float16 *a_lo, const H3Pass &w,
+template <bool HAS_NEXT, int RT>
+__device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[RT][2], const _Float16 *a_hi, const _Float16 *a_lo, const H3Pass &w,
                                              const H3Pass &next, H3Ring &ring, int lane) {
     constexpr int n_steps = H3_STEPS, pitch = H3_PITCH;
     const int aoff = (lane & 31) * pitch + 8 * (lane >> 5);
     auto load_a = [&](int s, H3FragA &f) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             f.h[rt] = *reinterpret_cast<const half8 *>(a_hi + rt * 32 * pitch + aoff + 16 * s);
             f.l[rt] = *reinterpret_cast<const half8 *>(a_lo + rt * 32 * pitch + aoff + 16 * s);
         }
@@ -472,10 +479,10 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* one LDS read */                         \
         }                                                                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 12 - (n_vmem) - (n_lds), 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * RT - (n_vmem) - (n_lds), 0);                      \
         H3_FENCE();                                                                                       \
     } while (0)
-    h3_zero(ac);
+    h3_zero<RT>(ac);
     H3FragB b3;
     H3FragA a0, a1;
     load_a(0, a0);
@@ -484,37 +491,37 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
     for (int s = 0; s < n_steps - 4; s += 4) {  // n_steps is a multiple of 4 (512 / 16 = 32)
         h3_load_b(w, n_steps, s + 3, b3);
         load_a(s + 1, a1);
-        h3_mma(ac, a0, ring.b0);
-        H3_SPREAD(4, 4);
+        h3_mma<RT>(ac, a0, ring.b0);
+        H3_SPREAD(4, 2 * RT);
         h3_load_b(w, n_steps, s + 4, ring.b0);
         load_a(s + 2, a0);
-        h3_mma(ac, a1, ring.b1);
-        H3_SPREAD(4, 4);
+        h3_mma<RT>(ac, a1, ring.b1);
+        H3_SPREAD(4, 2 * RT);
         h3_load_b(w, n_steps, s + 5, ring.b1);
         load_a(s + 3, a1);
-        h3_mma(ac, a0, ring.b2);
-        H3_SPREAD(4, 4);
+        h3_mma<RT>(ac, a0, ring.b2);
+        H3_SPREAD(4, 2 * RT);
         h3_load_b(w, n_steps, s + 6, ring.b2);
         load_a(s + 4, a0);
-        h3_mma(ac, a1, b3);
-        H3_SPREAD(4, 4);
+        h3_mma<RT>(ac, a1, b3);
+        H3_SPREAD(4, 2 * RT);
     }
     {   // the last four k-steps: the ring sets that fall free take the head of the next pass of the stream
         constexpr int s = n_steps - 4;
         h3_load_b(w, n_steps, s + 3, b3);
         load_a(s + 1, a1);
-        h3_mma(ac, a0, ring.b0);
-        H3_SPREAD(4, 4);
+        h3_mma<RT>(ac, a0, ring.b0);
+        H3_SPREAD(4, 2 * RT);
         if (HAS_NEXT) h3_load_b(next, n_steps, 0, ring.b0);
         load_a(s + 2, a0);
-        h3_mma(ac, a1, ring.b1);
-        H3_SPREAD(HAS_NEXT ? 4 : 0, 4);
+        h3_mma<RT>(ac, a1, ring.b1);
+        H3_SPREAD(HAS_NEXT ? 4 : 0, 2 * RT);
         if (HAS_NEXT) h3_load_b(next, n_steps, 1, ring.b1);
         load_a(s + 3, a1);
-        h3_mma(ac, a0, ring.b2);
-        H3_SPREAD(HAS_NEXT ? 4 : 0, 4);
+        h3_mma<RT>(ac, a0, ring.b2);
+        H3_SPREAD(HAS_NEXT ? 4 : 0, 2 * RT);
         if (HAS_NEXT) h3_load_b(next, n_steps, 2, ring.b2);
-        h3_mma(ac, a1, b3);
+        h3_mma<RT>(ac, a1, b3);
         H3_SPREAD(HAS_NEXT ? 4 : 0, 0);
     }
 #undef H3_SPREAD
@@ -524,33 +531,40 @@ __device__ __forceinline__ void gemm_pass_h3(f32x16 (&ac)[2][2], const _Float16 
 // a 512-wide hidden layer: this wave's 128 columns of all 64 samples.  `ring`: the first three k-steps of the layer,
 // requested by the caller (h3_prime_layer) once the previous layer's epilogue has let go of its registers -- they fly
 // while the workgroup meets at the barrier in front of this layer.
-__device__ __forceinline__ void h3_prime_layer(const unsigned short *layer, int wid, int lane, H3Ring &ring) {
-    h3_prime(h3_pass(layer, H3_STEPS, wid, 0, lane), H3_STEPS, ring);
+template <int NW> __device__ __forceinline__ void h3_prime_layer(const unsigned short *layer, int wid, int lane, H3Ring &ring) {
+    h3_prime(h3_pass<NW>(layer, H3_STEPS, wid, 0, lane), H3_STEPS, ring);
 }
-__device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[2][2][2], const _Float16 *a_hi, const _Float16 *a_lo,
+template <int NW, int RT>
+__device__ __forceinline__ void gemm_layer_h3(f32x16 (&acc)[8 / NW][RT][2], const _Float16 *a_hi, const _Float16 *a_lo,
                                               const unsigned short *layer, int wid, int lane, H3Ring &ring) {
-    const H3Pass w0 = h3_pass(layer, H3_STEPS, wid, 0, lane), w1 = h3_pass(layer, H3_STEPS, wid, 1, lane);
-    gemm_pass_h3<true>(acc[0], a_hi, a_lo, w0, w1, ring, lane);
-    gemm_pass_h3<false>(acc[1], a_hi, a_lo, w1, w1, ring, lane);
+    const H3Pass w0 = h3_pass<NW>(layer, H3_STEPS, wid, 0, lane);
+    if (NW == 4) {
+        const H3Pass w1 = h3_pass<NW>(layer, H3_STEPS, wid, 1, lane);
+        gemm_pass_h3<true, RT>(acc[0], a_hi, a_lo, w0, w1, ring, lane);
+        gemm_pass_h3<false, RT>(acc[8 / NW - 1], a_hi, a_lo, w1, w1, ring, lane);
+    } else {
+        gemm_pass_h3<false, RT>(acc[0], a_hi, a_lo, w0, w0, ring, lane);
+    }
 }
 
 // Linear(5 -> 512) of the step's inputs: one k-step (z rows padded to 16), both passes
-__device__ __forceinline__ void gemm_input_h3(f32x16 (&acc)[2][2][2], const _Float16 *z_hi, const _Float16 *z_lo,
+template <int NW, int RT>
+__device__ __forceinline__ void gemm_input_h3(f32x16 (&acc)[8 / NW][RT][2], const _Float16 *z_hi, const _Float16 *z_lo,
                                               const unsigned short *layer, int wid, int lane) {
     const int aoff = (lane & 31) * H3_ZPITCH + 8 * (lane >> 5);
     H3FragA a;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         a.h[rt] = *reinterpret_cast<const half8 *>(z_hi + rt * 32 * H3_ZPITCH + aoff);
         a.l[rt] = *reinterpret_cast<const half8 *>(z_lo + rt * 32 * H3_ZPITCH + aoff);
     }
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const H3Pass w = h3_pass(layer, 1, wid, pass, lane);
+    for (int pass = 0; pass < 8 / NW; ++pass) {
+        const H3Pass w = h3_pass<NW>(layer, 1, wid, pass, lane);
         H3FragB b;
         h3_load_b(w, 1, 0, b);
-        h3_zero(acc[pass]);
-        h3_mma(acc[pass], a, b);
+        h3_zero<RT>(acc[pass]);
+        h3_mma<RT>(acc[pass], a, b);
     }
 }
 
@@ -575,21 +589,22 @@ using half4v = __attribute__((ext_vector_type(4))) _Float16;
 // stored as h0 / s1: v = (acc s0 + b) / s1; 2 the first hidden layer -- its accumulators are those of h0 / s1: v = acc s1 + b.
 // `scale`: the per-sample {s0, 1 / s1, s1, 0} in LDS.  All three are 1 unless an input exceeds 2^15, and then exact powers
 // of two: the common case is bit for bit the unscaled arithmetic.
-template <bool TANH, bool LAST = false, int SCALE = 0>
-__device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[2][2][2], const float *bias,
+template <int NW, int RT, bool TANH, bool LAST = false, int SCALE = 0>
+__device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, const f32x16 (&acc)[8 / NW][RT][2], const float *bias,
                                                int wid, int lane, const float *w_out = nullptr, float (*yo)[3] = nullptr,
                                                const float *scale = nullptr) {
     F4 sc[2] = {{{1.f, 1.f, 1.f, 0.f}}, {{1.f, 1.f, 1.f, 0.f}}};
     if (SCALE != 0) {
         sc[0] = *reinterpret_cast<const F4 *>(scale + 4 * (lane & 31));
-        sc[1] = *reinterpret_cast<const F4 *>(scale + 4 * (32 + (lane & 31)));
+        if (RT == 2) sc[1] = *reinterpret_cast<const F4 *>(scale + 4 * (32 + (lane & 31)));
     }
-    const int lane_off = (lane & 31) * H3_PITCH + wid * 128 + 4 * (lane >> 5);
+    constexpr int COLS = MLP_H / NW;  // this wave's output features: 16 / NW column tiles of 32
+    const int lane_off = (lane & 31) * H3_PITCH + wid * COLS + 4 * (lane >> 5);
     _Float16 *const base[2][2] = {{a_hi + lane_off, a_hi + 32 * H3_PITCH + lane_off},
                                   {a_lo + lane_off, a_lo + 32 * H3_PITCH + lane_off}};
-    const float *bl = bias + wid * 128 + 4 * (lane >> 5);
+    const float *bl = bias + wid * COLS + 4 * (lane >> 5);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < 16 / NW; ++ct) {
         f32x2 bn[8];  // the biases of this lane's 16 features of the tile: four aligned 16-byte loads
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -599,14 +614,14 @@ __device__ __forceinline__ void store_layer_h3(_Float16 *a_hi, _Float16 *a_lo, c
         }
         F4 wo[3][4];  // LAST: the output layer's weights of the same 16 features, requested before the tanh arithmetic
         if (LAST) {
-            const float *wl = w_out + wid * 128 + 4 * (lane >> 5) + ct * 32;
+            const float *wl = w_out + wid * COLS + 4 * (lane >> 5) + ct * 32;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) wo[j][q] = *reinterpret_cast<const F4 *>(wl + j * MLP_H + 8 * q);
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             f32x2 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -671,27 +686,29 @@ __device__ unsigned long long g_mlp_phase[16];
     do {      \
     } while (0)
 #endif
-template <bool VIZ>
-__global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KParams<float> P, const MlpParams Q,
-                                                                       float *__restrict__ partials, const MlpViz V) {
+template <bool VIZ, int NW, int RT>
+__global__ __launch_bounds__(64 * NW, RT == 1 ? 2 : 1) void k_rollout_mlp_h3(const KParams<float> P, const MlpParams Q,
+                                                               float *__restrict__ partials, const MlpViz V) {
 #ifdef MPPI_STAMPS
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16 *a_hi = reinterpret_cast<_Float16 *>(smem);   // [64][520]
-    _Float16 *a_lo = a_hi + MLP_M * H3_PITCH;
-    _Float16 *z_hi = a_lo + MLP_M * H3_PITCH;              // [64][24] layer-0 input rows {x, y, yaw, v, w, 0 ...}: one k-step
-    _Float16 *z_lo = z_hi + MLP_M * H3_ZPITCH;
-    float *ypart = reinterpret_cast<float *>(z_lo + MLP_M * H3_ZPITCH);  // [4][64][4]
-    float *zscale = ypart + MLP_WAVES * MLP_M * 4;                      // [64][4] per-sample {s0, 1 / s1, s1, 0} (H3Scale)
-    float *ref_lds = zscale + MLP_M * 4;                                // [n_ref][4] when the path fits
+    constexpr int M = 32 * RT;  // samples of this workgroup's tile
+    _Float16 *a_hi = reinterpret_cast<_Float16 *>(smem);   // [M][520]
+    _Float16 *a_lo = a_hi + M * H3_PITCH;
+    _Float16 *z_hi = a_lo + M * H3_PITCH;                  // [M][24] layer-0 input rows {x, y, yaw, v, w, 0 ...}: one k-step
+    _Float16 *z_lo = z_hi + M * H3_ZPITCH;
+    float *ypart = reinterpret_cast<float *>(z_lo + M * H3_ZPITCH);  // [NW][M][4]
+    float *zscale = ypart + NW * M * 4;                             // [M][4] per-sample {s0, 1 / s1, s1, 0} (H3Scale)
+    float *ref_lds = zscale + M * 4;                                // [n_ref][4] when the path fits
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int k0 = ((int)blockIdx.x + (VIZ ? V.block0 : 0)) * MLP_M, k = k0 + lane;
-    const KParams<float> PL = mlp_stage_path(P, ref_lds);
+    const int k0 = ((int)blockIdx.x + (VIZ ? V.block0 : 0)) * M, k = k0 + lane;
+    const KParams<float> PL = mlp_stage_path(P, ref_lds, RT == 1 ? H3_REF_LDS_32 : MLP_REF_LDS_MAX);
     const DevState sv = load_state(P, P.st);
     const ObsLanes<float> obs = load_obstacles(P, lane);
-    if (!VIZ && k0 + MLP_M <= sv.k_start) return;
-    const bool valid = k < P.K, live = valid && k >= sv.k_start;
+    if (!VIZ && k0 + M <= sv.k_start) return;
+    const bool in_tile = lane < M;  // (a 32-sample tile: the upper half of wave 0 carries no sample)
+    const bool valid = in_tile && k < P.K, live = valid && k >= sv.k_start;
     // VIZ: the workgroup behind the samples' carries the nominal sequence in its lane 0
     const bool eval = VIZ && V.ex != nullptr, eval_row = eval && k < V.en;
     const bool opt_row = VIZ && !eval && k0 >= P.K && lane == 0 && V.opt != nullptr;
@@ -702,8 +719,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
     if (eval_row) { L.x = V.ex[3 * k]; L.y = V.ex[3 * k + 1]; L.yaw = V.ex[3 * k + 2]; }
     const int n_steps = eval ? 1 : P.T;
     const bool exploit = (k + P.k_offset) < P.n_exploit;
-    f32x16 acc[2][2][2];
-    if (wid == 0) {  // the padding of the layer-0 rows stays zero
+    f32x16 acc[8 / NW][RT][2];
+    if (wid == 0 && in_tile) {  // the padding of the layer-0 rows stays zero
         for (int q = 0; q < H3_ZPITCH; ++q) { z_hi[lane * H3_ZPITCH + q] = (_Float16)0.f; z_lo[lane * H3_ZPITCH + q] = (_Float16)0.f; }
     }
     for (int t = 0; t < n_steps; ++t) {
@@ -715,44 +732,46 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
             else mlp_controls(P, iter, k, t, valid, exploit, u0, u1, v0, v1);
             const float z[5] = {L.x, L.y, L.yaw, v0, v1};
             const H3Scale hs = h3_scale(z, Q.in_gain, Q.in_bias);
-            *reinterpret_cast<F4 *>(zscale + 4 * lane) = F4{{hs.s0, hs.inv_s1, hs.s1, 0.f}};
+            if (in_tile) {
+                *reinterpret_cast<F4 *>(zscale + 4 * lane) = F4{{hs.s0, hs.inv_s1, hs.s1, 0.f}};
 #pragma unroll
-            for (int q = 0; q < 5; ++q) split_h3(z[q] * hs.inv_s0, z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
+                for (int q = 0; q < 5; ++q) split_h3(z[q] * hs.inv_s0, z_hi[lane * H3_ZPITCH + q], z_lo[lane * H3_ZPITCH + q]);
+            }
         }
         __syncthreads();
         PH(0);
-        gemm_input_h3(acc, z_hi, z_lo, Q.h3_w_in, wid, lane);
+        gemm_input_h3<NW, RT>(acc, z_hi, z_lo, Q.h3_w_in, wid, lane);
         PH(1);
-        store_layer_h3<false, false, 1>(a_hi, a_lo, acc, Q.b_in, wid, lane, nullptr, nullptr, zscale);
+        store_layer_h3<NW, RT, false, false, 1>(a_hi, a_lo, acc, Q.b_in, wid, lane, nullptr, nullptr, zscale);
         H3Ring ring;
-        h3_prime_layer(Q.h3_w_h[0], wid, lane, ring);
+        h3_prime_layer<NW>(Q.h3_w_h[0], wid, lane, ring);
         PH(2);
         __syncthreads();
         PH(3);
         for (int l = 0; l < 2; ++l) {
-            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane, ring);
+            gemm_layer_h3<NW, RT>(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane, ring);
             PH(4);
             __syncthreads();
             PH(5);
-            if (l == 0) store_layer_h3<true, false, 2>(a_hi, a_lo, acc, Q.b_h[l], wid, lane, nullptr, nullptr, zscale);
-            else store_layer_h3<true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
-            h3_prime_layer(Q.h3_w_h[l + 1], wid, lane, ring);
+            if (l == 0) store_layer_h3<NW, RT, true, false, 2>(a_hi, a_lo, acc, Q.b_h[l], wid, lane, nullptr, nullptr, zscale);
+            else store_layer_h3<NW, RT, true>(a_hi, a_lo, acc, Q.b_h[l], wid, lane);
+            h3_prime_layer<NW>(Q.h3_w_h[l + 1], wid, lane, ring);
             PH(6);
             __syncthreads();
             PH(7);
         }
         {   // the third hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's 128 of the 512 inputs
-            gemm_layer_h3(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane, ring);
+            gemm_layer_h3<NW, RT>(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane, ring);
             PH(4);
             float yo[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            store_layer_h3<true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
+            store_layer_h3<NW, RT, true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {  // the two lane halves hold the two halves of a sample's features
+            for (int rt = 0; rt < RT; ++rt) {  // the two lane halves hold the two halves of a sample's features
                 F4 o;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) o.v[j] = yo[rt][j] + __shfl_xor(yo[rt][j], 32);
                 o.v[3] = 0.f;
-                if (lane < 32) *reinterpret_cast<F4 *>(ypart + (wid * MLP_M + rt * 32 + lane) * 4) = o;
+                if (lane < 32) *reinterpret_cast<F4 *>(ypart + (wid * M + rt * 32 + lane) * 4) = o;
             }
         }
         PH(8);
@@ -760,8 +779,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp_h3(const KPar
         if (wid == 0) {
             float r0 = Q.b_out[0], r1 = Q.b_out[1], r2 = Q.b_out[2];
 #pragma unroll
-            for (int w = 0; w < MLP_WAVES; ++w) {
-                const F4 o = *reinterpret_cast<const F4 *>(ypart + (w * MLP_M + lane) * 4);
+            for (int w = 0; w < NW; ++w) {
+                const F4 o = *reinterpret_cast<const F4 *>(ypart + (w * M + (in_tile ? lane : 0)) * 4);
                 r0 += o.v[0];
                 r1 += o.v[1];
                 r2 += o.v[2];
@@ -790,12 +809,33 @@ extern "C" int mppi_debug_mlp_phases(unsigned long long *out) {
 }
 #endif
 
-int mlp_blocks(int K) { return (K + MLP_M - 1) / MLP_M; }
+// The forms of the f16-split rollout kernel (MPPI_MLP_FORM, for A/B runs): "4x64" one wave per SIMD, "8x64" two waves per
+// SIMD, both on one 64-sample tile per workgroup.  (Tried and dropped: 32-sample tiles with two workgroups per CU, so that one
+// workgroup's epilogues run under the other's GEMMs -- every weight byte then feeds half as many MFMAs, the weight stream
+// from L2 doubles to ~85 B per clock and CU, and the launch went from 6.3 to 8.7 ms.)
+enum { H3_FORM_4x64 = 0, H3_FORM_8x64 = 1 };
+static int h3_form() {
+    static const int f = [] {
+        const char *e = getenv("MPPI_MLP_FORM");
+        if (e && !strcmp(e, "4x64")) return (int)H3_FORM_4x64;
+        if (e && !strcmp(e, "8x64")) return (int)H3_FORM_8x64;
+        return (int)H3_FORM_DEFAULT;
+    }();
+    return f;
+}
+// samples per workgroup (= per softmin record) of the rollout kernel that serves Q
+int mlp_tile(const MlpParams &) { return MLP_M; }
+int mlp_blocks(int K, int tile) { return (K + tile - 1) / tile; }
+
+static size_t h3_shmem(int nw, int rt) {
+    const int m = 32 * rt;
+    return sizeof(_Float16) * 2 * (m * H3_PITCH + m * H3_ZPITCH) + sizeof(float) * (nw + 1) * m * 4 +
+           sizeof(float) * 4 * (rt == 1 ? H3_REF_LDS_32 : MLP_REF_LDS_MAX);
+}
 
 static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *partials, const MlpViz *viz, hipStream_t s) {
     const size_t ref_lds = sizeof(float) * 4 * MLP_REF_LDS_MAX;  // the path (mlp_stage_path)
     const size_t shmem_f32 = sizeof(float) * (MLP_M * MLP_PITCH + MLP_M * 8 + MLP_WAVES * MLP_M * 4) + ref_lds;
-    const size_t shmem_h3 = sizeof(_Float16) * 2 * (MLP_M * H3_PITCH + MLP_M * H3_ZPITCH) + sizeof(float) * (MLP_WAVES + 1) * MLP_M * 4 + ref_lds;
     // (the attribute belongs to the device's copy of the code object: one process may drive several GPUs)
     static bool attr_set[64] = {};
     int dev = 0;
@@ -803,24 +843,34 @@ static void launch_mlp_any(const KParams<float> &P, const MlpParams &Q, void *pa
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem_f32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)shmem_h3);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)shmem_h3);
+#define H3_ATTR(VIZ_, NW_, RT_)                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_mlp_h3<VIZ_, NW_, RT_>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h3_shmem(NW_, RT_))
+        H3_ATTR(false, 4, 2); H3_ATTR(true, 4, 2); H3_ATTR(false, 8, 2); H3_ATTR(true, 8, 2);
+#undef H3_ATTR
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    if (viz)  // the samples' workgroups (when their trajectories are wanted) and one for the nominal sequence (likewise)
-        hipLaunchKernelGGL(k_rollout_mlp_h3<true>,
-                           dim3(viz->ex ? mlp_blocks(viz->en) : (viz->smp ? mlp_blocks(P.K) : 0) + (viz->opt ? 1 : 0)),
-                           dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials, *viz);
-    else if (Q.use_h3)
-        hipLaunchKernelGGL(k_rollout_mlp_h3<false>, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_h3, s, P, Q, (float *)partials,
-                           MlpViz{nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr, nullptr, 0});
-    else
-        hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
+    const MlpViz none{nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr, nullptr, 0};
+    const int form = h3_form();
+    if (viz) {  // the samples' workgroups (when their trajectories are wanted) and one for the nominal sequence (likewise);
+                // always 64-sample tiles
+        const dim3 grid(viz->ex ? mlp_blocks(viz->en, MLP_M) : (viz->smp ? mlp_blocks(P.K, MLP_M) : 0) + (viz->opt ? 1 : 0));
+        if (form == H3_FORM_8x64) hipLaunchKernelGGL((k_rollout_mlp_h3<true, 8, 2>), grid, dim3(512), h3_shmem(8, 2), s, P, Q, (float *)partials, *viz);
+        else hipLaunchKernelGGL((k_rollout_mlp_h3<true, 4, 2>), grid, dim3(256), h3_shmem(4, 2), s, P, Q, (float *)partials, *viz);
+    } else if (Q.use_h3) {
+        const dim3 grid(mlp_blocks(P.K, mlp_tile(Q)));
+        if (form == H3_FORM_8x64) hipLaunchKernelGGL((k_rollout_mlp_h3<false, 8, 2>), grid, dim3(512), h3_shmem(8, 2), s, P, Q, (float *)partials, none);
+        else hipLaunchKernelGGL((k_rollout_mlp_h3<false, 4, 2>), grid, dim3(256), h3_shmem(4, 2), s, P, Q, (float *)partials, none);
+    } else {
+        hipLaunchKernelGGL(k_rollout_mlp, dim3(mlp_blocks(P.K, MLP_M)), dim3(64 * MLP_WAVES), shmem_f32, s, P, Q, (float *)partials);
+    }
 }
 
-const char *mlp_kernel_name(const MlpParams &Q) { return Q.use_h3 ? "k_rollout_mlp_h3<false>" : "k_rollout_mlp("; }
+const char *mlp_kernel_name(const MlpParams &Q) {
+    if (!Q.use_h3) return "k_rollout_mlp(";
+    const int form = h3_form();
+    return form == H3_FORM_8x64 ? "k_rollout_mlp_h3<false, 8, 2>" : "k_rollout_mlp_h3<false, 4, 2>";
+}
 void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *partials, hipStream_t s) {
     launch_mlp_any(P, Q, partials, nullptr, s);
 }
@@ -829,7 +879,7 @@ void launch_rollout_mlp(const KParams<float> &P, const MlpParams &Q, void *parti
 void launch_viz_mlp(const KParams<float> &P, const MlpParams &Q, const float *u_before, const float *u_upd, long long iter,
                     float *opt, float *smp, hipStream_t s) {
     if (!opt && !smp) return;
-    const MlpViz v{u_before, u_upd, opt, smp, (unsigned)iter, smp ? 0 : mlp_blocks(P.K), nullptr, nullptr, nullptr, 0};
+    const MlpViz v{u_before, u_upd, opt, smp, (unsigned)iter, smp ? 0 : mlp_blocks(P.K, MLP_M), nullptr, nullptr, nullptr, 0};
     launch_mlp_any(P, Q, nullptr, &v, s);
 }
 
