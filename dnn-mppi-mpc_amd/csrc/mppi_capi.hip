@@ -715,7 +715,7 @@ static void launch_front(mppi_handle *h, const KParams<R> &P, double beta, hipSt
     if (tm) hipEventRecord(next_event(h), s);
     if (tm) hipEventRecord(next_event(h), s);
     if (!mlp && !h->fused) launch_reduce<R>(P, h->d_partials, h->n_blocks, s);
-    // (records per agent this launch left: the handle's count, or fewer when the streaming kernel served a noise tensor)
+    // (records per agent this launch left: the handle's count, or the streaming kernel's when that one served)
     const int n_part = (!mlp && h->fused) ? fused_records<R>(P) : h->n_part;
     *recs = h->d_partials;
     *heads = h->d_heads;

@@ -979,7 +979,10 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
 // (s_waitcnt vmcnt(0))
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename R, bool MULTI, bool OBS>
+// PHILOX: the same loop with the noise drawn in registers (one Philox4x32 block per lane feeds its two steps, as in
+// k_rollout_dual) -- the frozen-index `S[k] =` form then also pays one search per sample instead of one per lane and step,
+// no workgroup barrier per 32 samples and one record per workgroup: 32 batched config-2 agents 63 -> ~35 us per launch.
+template <typename R, bool MULTI, bool OBS, bool PHILOX>
 __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rollout_stream(const DevState *st_pre, const KParams<R> P,
                                                                                             R *__restrict__ partials, int n_pass) {
     constexpr int ROWS = DUAL_SAMPLES;  // half-waves of the workgroup = samples in flight
@@ -997,13 +1000,18 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
     const int c = sv.c, T = P.T, K = P.K, t0 = 2 * l32, t1 = t0 + 1;
     const bool a0 = t0 < T, a1 = t1 < T;
     const int n_batch = (K + ROWS - 1) / ROWS, b0 = (int)blockIdx.x * n_pass;
-    const float *__restrict__ eps = eps_tensor(P, (unsigned)sv.iter, agent);
+    const float *__restrict__ eps = PHILOX ? nullptr : eps_tensor(P, (unsigned)sv.iter, agent);
+    const unsigned iter = (unsigned)sv.iter;
     // Unconditional loads from clamped addresses (what lies beyond the horizon or the last sample is masked where it is
     // used): a load under a per-lane condition makes the compiler wait for it at the end of the branch, i.e. right away.
     // Two 8-byte loads per lane (a row of odd length leaves its second half 8-byte aligned only).
     const float *__restrict__ row0 = eps + (size_t)(t0 < T ? t0 : T - 1) * 2, *__restrict__ row1 = eps + (size_t)(t1 < T ? t1 : T - 1) * 2;
     auto request = [&](int batch, float4 &e) {
         int k = batch * ROWS + sidx;
+        if (PHILOX) {  // (drawn, not fetched: see the loop)
+            e = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
         k = k < K ? k : K - 1;
         const size_t off = (size_t)k * T * 2;
         const float2 ea = *reinterpret_cast<const float2 *>(row0 + off), eb = *reinterpret_cast<const float2 *>(row1 + off);
@@ -1034,8 +1042,14 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
         R v00, v01, v10, v11;
         {   // (the noise waits in this lane's own LDS slot until the sample's weight is known; the nominal controls come from
             // LDS per batch: eight registers fewer across the arithmetic below, which keeps the kernel at 64 VGPRs)
-            const float4 e = e_next;
+            float4 e = e_next;
             request(batch + 1, e_next);  // (past the last batch: a clamped re-read, cheaper than a branch around the loads)
+            if (PHILOX) {
+                unsigned r[4];
+                px::philox4x32_10((unsigned)(k + P.k_offset), (unsigned)l32, iter, (unsigned)(P.noise_stream + agent), P.seed_lo, P.seed_hi, r);
+                px::box_muller(r[0], r[1], P.chol, e.x, e.y);
+                px::box_muller(r[2], r[3], P.chol, e.z, e.w);
+            }
             *reinterpret_cast<float4 *>(&sh_raw[sidx][4 * l32]) = e;
             const VecT4<R> uu = *reinterpret_cast<const VecT4<R> *>(&sh_u[4 * l32]);  // u<step><channel>
             v00 = exploit ? uu.x + (R)e.x : (R)e.x; v01 = exploit ? uu.y + (R)e.y : (R)e.y;  // :116-119
@@ -2239,10 +2253,10 @@ int fused_blocks(int K, int T, int layout) {
     return (K + per_block - 1) / per_block;
 }
 
-// The streaming kernel serves: noise from a tensor, diff-drive, the two-samples-per-wave layout, frozen index, `S[k] =`.
+// The streaming kernel serves: diff-drive, the two-samples-per-wave layout, frozen index, `S[k] =`, windows of <= 32 candidates.
 // Batches of 32 samples per workgroup: as many as leave about 1024 workgroups (two rounds of two per CU), at most 16.
 template <typename R> static int stream_passes(const KParams<R> &P) {
-    if (P.eps == nullptr || P.model != MODEL_DIFF || P.sequential || P.accumulate || P.T > 64 || P.window > 32 ||
+    if (P.model != MODEL_DIFF || P.sequential || P.accumulate || P.T > 64 || P.window > 32 ||
         (P.layout & LAYOUT_KIND) != LAYOUT_DUAL)
         return 0;
     static const bool off = getenv("MPPI_NO_STREAM") != nullptr;  // (A/B runs)
@@ -2265,13 +2279,15 @@ template int fused_records<double>(const KParams<double> &);
 template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const KParams<R> &P, R *partials, hipStream_t s) {
     if (const int np = stream_passes(P)) {
         const dim3 sgrid(fused_records(P), MULTI ? P.n_agents : 1);
-        if (P.obstacle_model != OBS_NONE) {
-            MPPI_NOTE_KERNEL("k_rollout_stream<%s, %s, true>", type_name<R>(), tf(MULTI));
-            hipLaunchKernelGGL((k_rollout_stream<R, MULTI, true>), sgrid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials, np);
-        } else {
-            MPPI_NOTE_KERNEL("k_rollout_stream<%s, %s, false>", type_name<R>(), tf(MULTI));
-            hipLaunchKernelGGL((k_rollout_stream<R, MULTI, false>), sgrid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials, np);
-        }
+#define MPPI_LAUNCH_STREAM(OBS_, PHILOX_)                                                                              \
+    do {                                                                                                               \
+        MPPI_NOTE_KERNEL("k_rollout_stream<%s, %s, %s, %s>", type_name<R>(), tf(MULTI), tf(OBS_), tf(PHILOX_));        \
+        hipLaunchKernelGGL((k_rollout_stream<R, MULTI, OBS_, PHILOX_>), sgrid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials, np); \
+    } while (0)
+        const bool obs = P.obstacle_model != OBS_NONE;
+        if (P.use_philox) { if (obs) MPPI_LAUNCH_STREAM(true, true); else MPPI_LAUNCH_STREAM(false, true); }
+        else { if (obs) MPPI_LAUNCH_STREAM(true, false); else MPPI_LAUNCH_STREAM(false, false); }
+#undef MPPI_LAUNCH_STREAM
         return;
     }
     const dim3 grid(fused_blocks(P.K, P.T, P.layout), MULTI ? P.n_agents : 1);

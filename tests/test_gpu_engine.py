@@ -975,6 +975,10 @@ def test_rollout_kernel_name_follows_the_layout():
     d = pkg.MPPIAlgorithms(**dd_kwargs(16384, 50), precision="f32", seed=1, waypoint_mode="frozen")
     d._engine.set_state(np.zeros(3))
     d._engine.run_closed_loop(1)
+    assert d._engine.rollout_kernel() == "k_rollout_stream<float, false, false, true>"  # frozen index, `S[k] =`: streamed
+    d = pkg.MPPIAlgorithms(**dd_kwargs(16384, 50), precision="f32", seed=1)  # the sequential index: two samples per wave
+    d._engine.set_state(np.zeros(3))
+    d._engine.run_closed_loop(1)
     assert d._engine.rollout_kernel().startswith("k_rollout_dual<float, 0, 2, false, ")
 
 
