@@ -229,7 +229,7 @@ def pmc_kernel(pmc, kernel, workgroups):
     `workgroups` workgroups.  None when there is none: a figure of another kernel or launch size is never quoted."""
     if pmc is None:
         return None
-    hits = [e for e in pmc.get("kernels", []) if kernel in e["kernel"] and e["grid"] // e["wg"] == workgroups]
+    hits = [e for e in pmc.get("kernels", []) if kernel in e["kernel"] and (workgroups is None or e["grid"] // e["wg"] == workgroups)]
     return max(hits, key=lambda e: e.get("launches_averaged", 0)) if hits else None
 
 
@@ -322,10 +322,9 @@ def eps_hbm_line(args):
     read = 8.0 * K * T * n_agents  # what the rollout really has to fetch: one pass over the noise (the second stays in registers)
     build_id = pkg.source_id()
     h = out["hbm"]
-    layout = eng.counters()["rollout_layout"]
-    per_wg = 16 * (2 if (layout & 3) == 1 else 1) * (2 if layout & 4 else 1)
-    pmc, pmc_src = stamped_profile("pmc_eps_" + args.workload, build_id)
-    pk = pmc_kernel(pmc, h["kernel"], ((K + per_wg - 1) // per_wg) * n_agents) if h["kernel"] else None
+    pmc, pmc_src = stamped_profile("pmc", build_id)
+    # (the kernel that serves a noise tensor runs in this command only: its one entry is this launch size)
+    pk = pmc_kernel(pmc, h["kernel"], None) if h["kernel"] else None
     traffic = None
     if pk is not None and "FETCH_SIZE" in pk["counters"] and "WRITE_SIZE" in pk["counters"]:
         traffic = (2.0 * pk["counters"]["FETCH_SIZE"] + pk["counters"]["WRITE_SIZE"]) * 1024.0
@@ -740,9 +739,15 @@ def main():
                     "kernel_instantiation": ran,
                     # rocprofv3 --pmc pass of this command (profiles/): the matrix pipe's busy cycles over the launch's
                     # cycles on all 1024 SIMDs, and the MFMA operations the counters saw against the algorithmic count
+                    # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 matrix pipes (32 per 32x32x16 MFMA);
+                    # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (it equals 8 x the launch's duration x the shader clock)
                     "MfmaUtil": (None if pk is None or "SQ_VALU_MFMA_BUSY_CYCLES" not in pk["counters"] or
                                  not pk["counters"].get("GRBM_GUI_ACTIVE") else
-                                 pk["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (pk["counters"]["GRBM_GUI_ACTIVE"] * 1024.0)),
+                                 pk["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (pk["counters"]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)),
+                    "shader_clock_GHz_in_kernel": (None if pk is None or not pk["counters"].get("GRBM_GUI_ACTIVE") or not t_roll else
+                                                   pk["counters"]["GRBM_GUI_ACTIVE"] / 8.0 / t_roll * 1e-9),
+                    "mfma_flop_counted": (None if pk is None or "SQ_INSTS_VALU_MFMA_MOPS_F16" not in pk["counters"] else
+                                          512.0 * pk["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F16"]),
                     "pmc": None if pk is None else pk["counters"],
                     "kernel_us": None if t_roll is None else 1e6 * t_roll, "kernel_us_method": method,
                     "kernel_us_marginal": 1e6 * t_marg, "kernel_us_event_pair": 1e6 * ev_pair,

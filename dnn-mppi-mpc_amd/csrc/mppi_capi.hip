@@ -371,8 +371,9 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
     if (!h || !w_in || !b_in || !w_hidden || !b_hidden || !w_out || !b_out)
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp: null argument");
     if (h->cfg.model != MPPI_MODEL_DIFFDRIVE_MLP) FAIL(h, MPPI_ERR_STATE, "mppi_set_mlp needs MPPI_MODEL_DIFFDRIVE_MLP");
-    if (hidden != 512 || n_hidden != 3)
-        FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: only Linear(5,512) -> 3 x Linear(512,512) -> Linear(512,3) is built");
+    if (hidden != 512 || (n_hidden != 3 && n_hidden != 2))
+        FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: Linear(5,512) -> n x [Linear(512,512), tanh] -> Linear(512,3) with n = 3 or 2 is built "
+                                "(got hidden = %d, n = %d)", hidden, n_hidden);
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
     const size_t n_in = 16 * 1 * 64 * 4, n_h = 16 * 64 * 64 * 4, total = n_in + 512 + 3 * (n_h + 512) + 3 * 512;
@@ -381,10 +382,14 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
     const size_t o_win = o; pack_linear(w_in, 5, host.data() + o); o += n_in;
     const size_t o_bin = o; memcpy(host.data() + o, b_in, 512 * sizeof(float)); o += 512;
     size_t o_wh[3], o_bh[3];
-    for (int l = 0; l < 3; ++l) {
-        if (!w_hidden[l] || !b_hidden[l]) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp: null hidden layer %d", l);
-        o_wh[l] = o; pack_linear(w_hidden[l], 512, host.data() + o); o += n_h;
-        o_bh[l] = o; memcpy(host.data() + o, b_hidden[l], 512 * sizeof(float)); o += 512;
+    for (int l = 0; l < 3; ++l) {  // (a two-layer model leaves the third slot unused)
+        o_wh[l] = o; o_bh[l] = o + n_h;
+        if (l < n_hidden) {
+            if (!w_hidden[l] || !b_hidden[l]) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp: null hidden layer %d", l);
+            pack_linear(w_hidden[l], 512, host.data() + o);
+            memcpy(host.data() + o + n_h, b_hidden[l], 512 * sizeof(float));
+        }
+        o += n_h + 512;
     }
     const size_t o_wo = o; memcpy(host.data() + o, w_out, 3 * 512 * sizeof(float)); o += 3 * 512;
     if (!h->d_mlp) HIPCHECK(h, hipMalloc((void **)&h->d_mlp, total * sizeof(float)));
@@ -398,7 +403,7 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
         const size_t n_in16 = (size_t)2 * 16 * 1 * 64 * 8, n_h16 = (size_t)2 * 16 * 32 * 64 * 8, tot16 = n_in16 + 3 * n_h16;
         std::vector<unsigned short> h16(tot16);
         pack_linear_h3(w_in, 5, h16.data());
-        for (int l = 0; l < 3; ++l) pack_linear_h3(w_hidden[l], 512, h16.data() + n_in16 + (size_t)l * n_h16);
+        for (int l = 0; l < n_hidden; ++l) pack_linear_h3(w_hidden[l], 512, h16.data() + n_in16 + (size_t)l * n_h16);
         if (!h->d_mlp16) HIPCHECK(h, hipMalloc((void **)&h->d_mlp16, tot16 * sizeof(unsigned short)));
         HIPCHECK(h, hipMemcpy(h->d_mlp16, h16.data(), tot16 * sizeof(unsigned short), hipMemcpyHostToDevice));
         h->mlp.h3_w_in = h->d_mlp16;
@@ -410,7 +415,7 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
         // pre-activations of any magnitude are handled inside the split kernel (per-sample power-of-two scales).
         double wmax = 0.0;
         for (int i = 0; i < 512 * 5; ++i) wmax = fmax(wmax, fabs((double)w_in[i]));
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < n_hidden; ++l)
             for (size_t i = 0; i < (size_t)512 * 512; ++i) wmax = fmax(wmax, fabs((double)w_hidden[l][i]));
         if (!(wmax <= 65504.0)) {  // (also NaN)
             h->mlp.use_h3 = 0;
@@ -430,6 +435,7 @@ extern "C" int mppi_set_mlp(mppi_handle *h, int32_t hidden, int32_t n_hidden, co
         h->mlp.in_gain = (float)(gain * (1.0 + 1e-6));
         h->mlp.in_bias = (float)(bias * (1.0 + 1e-6));
     }
+    h->mlp.n_hidden = n_hidden;
     h->n_part = mlp_blocks(h->cfg.K, mlp_tile(h->mlp));  // records the rollout kernel that serves this model leaves
     h->mlp_set = true;
     return MPPI_OK;
@@ -442,7 +448,7 @@ extern "C" int mppi_set_mlp_scaled(mppi_handle *h, int32_t hidden, int32_t n_hid
     if (!h || !w_in || !b_in || !w_out || !b_out) FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp_scaled: null argument");
     if ((in_mean == nullptr) != (in_scale == nullptr) || (out_mean == nullptr) != (out_scale == nullptr))
         FAIL(h, MPPI_ERR_BAD_ARG, "mppi_set_mlp_scaled: a mean without its scale (or the reverse)");
-    if (hidden != 512) FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: only Linear(5,512) -> 3 x Linear(512,512) -> Linear(512,3) is built");
+    if (hidden != 512) FAIL(h, MPPI_ERR_SHAPE, "mppi_set_mlp: the hidden width must be 512 (got %d)", hidden);
     std::vector<float> wi(w_in, w_in + (size_t)hidden * 5), bi(b_in, b_in + hidden), wo(w_out, w_out + (size_t)3 * hidden),
         bo(b_out, b_out + 3);
     if (in_mean) {

@@ -167,6 +167,8 @@ struct MlpParams {
     // |W_in z + b_in|_inf <= in_gain |z|_inf + in_bias: the split kernel derives the per-sample power-of-two scale of the
     // first layer's output from it, so that no f16 half overflows whatever the magnitude of the inputs
     float in_gain, in_bias;
+    int n_hidden;  // hidden Linear(512, 512) + tanh layers: 3 (the architecture train/train_diff_mlp.py:13-36 builds) or 2
+                   // (the reference's older checkpoints, saved_models/mlp_diff.pth, mlp_diff_300x100.pth, ..._v2.pth)
 };
 
 struct VizParams {

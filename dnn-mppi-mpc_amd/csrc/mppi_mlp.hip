@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES, 1) void k_rollout_mlp(const KParams
         store_layer<false>(act, acc, Q.b_in, wid, lane);
         __syncthreads();
         // hidden_layer[i]: tanh(Linear(512 -> 512)) (:33-34)
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < Q.n_hidden; ++l) {
             gemm_layer(acc, act, MLP_PITCH, Q.w_h[l], MLP_GROUPS, wid, lane);
             __syncthreads();  // every wave has read the previous activations
             store_layer<true>(act, acc, Q.b_h[l], wid, lane);
@@ -748,7 +748,8 @@ __global__ __launch_bounds__(64 * NW, RT == 1 ? 2 : 1) void k_rollout_mlp_h3(con
         PH(2);
         __syncthreads();
         PH(3);
-        for (int l = 0; l < 2; ++l) {
+        const int l_last = Q.n_hidden - 1;  // (2 or 3 hidden layers: mppi_set_mlp)
+        for (int l = 0; l < l_last; ++l) {
             gemm_layer_h3<NW, RT>(acc, a_hi, a_lo, Q.h3_w_h[l], wid, lane, ring);
             PH(4);
             __syncthreads();
@@ -760,11 +761,11 @@ __global__ __launch_bounds__(64 * NW, RT == 1 ? 2 : 1) void k_rollout_mlp_h3(con
             __syncthreads();
             PH(7);
         }
-        {   // the third hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's 128 of the 512 inputs
-            gemm_layer_h3<NW, RT>(acc, a_hi, a_lo, Q.h3_w_h[2], wid, lane, ring);
+        {   // the last hidden layer and out_layer (Linear(512 -> 3), :35) in its epilogue: this wave's share of the 512 inputs
+            gemm_layer_h3<NW, RT>(acc, a_hi, a_lo, Q.h3_w_h[l_last], wid, lane, ring);
             PH(4);
             float yo[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            store_layer_h3<NW, RT, true, true>(a_hi, a_lo, acc, Q.b_h[2], wid, lane, Q.w_out, yo);
+            store_layer_h3<NW, RT, true, true>(a_hi, a_lo, acc, Q.b_h[l_last], wid, lane, Q.w_out, yo);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {  // the two lane halves hold the two halves of a sample's features
                 F4 o;

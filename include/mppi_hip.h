@@ -158,8 +158,9 @@ int mppi_set_obstacles(mppi_handle *h, const double *xyr, int32_t m);
 /*
  * Weights of the residual model `MultiLayerPerceptron` (train/train_diff_mlp.py:13-36), host float arrays in the
  * checkpoint's own layout (saved_models/mlp_diff_300x100_3l.pth): input_layer.weight [512,5], .bias [512];
- * hidden_layer.{0,1,2}.weight [512,512], .bias [512]; out_layer.weight [3,512], .bias [3].
- * hidden must be 512 and n_hidden 3 (the architecture the reference trains).
+ * hidden_layer.{0..n_hidden-1}.weight [512,512], .bias [512]; out_layer.weight [3,512], .bias [3].
+ * hidden must be 512; n_hidden 3 (the architecture the reference trains, mlp_diff_300x100_3l*.pth) or 2 (its older
+ * checkpoints mlp_diff.pth, mlp_diff_300x100.pth, mlp_diff_300x100_v2.pth: hidden_layer.{0,1}).
  * Numeric range: the default kernel carries weights, inputs and activations as pairs of f16 numbers.  Inputs [x, y, yaw, v, w]
  * and first-layer pre-activations of ANY finite magnitude are handled (per-sample power-of-two scales inside the kernel); a
  * WEIGHT beyond +-65504 cannot be, so such a model is served by the f32-input MFMA kernel instead (about 3x slower, same

@@ -326,23 +326,30 @@ if __name__ == "__main__" and "filters" in sys.argv[1:]:
 # itself does not exist on the GPU box.
 # ---------------------------------------------------------------------------------------
 
-def gen_config5():
+def gen_config5(TWO_LAYER=False):
+    """TWO_LAYER: the reference's older checkpoints (saved_models/mlp_diff_300x100.pth: hidden_layer.{0,1} only) through the
+    same class -- its forward walks `self.hidden_layer` (train/train_diff_mlp.py:33-34), so the module list is cut to the two
+    layers the checkpoint holds; nothing else changes."""
     import types
 
     import torch
     from controllers.mppi_differential_drive import MPPIAlgorithms as DD
     from train.train_diff_mlp import MultiLayerPerceptron
 
-    sd = torch.load("/root/reference/saved_models/mlp_diff_300x100_3l.pth", map_location="cpu", weights_only=True)
+    ckpt = "mlp_diff_300x100" if TWO_LAYER else "mlp_diff_300x100_3l"
+    sd = torch.load(f"/root/reference/saved_models/{ckpt}.pth", map_location="cpu", weights_only=True)
     os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, "mlp_diff_300x100_3l_weights.npz"),
+    np.savez_compressed(os.path.join(OUT, f"{ckpt}_weights.npz"),
                         **{k: v.numpy() for k, v in sd.items()})
-    net = MultiLayerPerceptron(5)
-    net.load_state_dict(sd)
-    net = net.double().eval()  # f64 like the NumPy controller around it (the f32 forward is recorded beside it)
-    net32 = MultiLayerPerceptron(5)
-    net32.load_state_dict(sd)
-    net32.eval()
+
+    def make_net():
+        n = MultiLayerPerceptron(5)
+        if TWO_LAYER:
+            n.hidden_layer = torch.nn.ModuleList(list(n.hidden_layer)[:2])
+        n.load_state_dict(sd)
+        return n
+    net = make_net().double().eval()  # f64 like the NumPy controller around it (the f32 forward is recorded beside it)
+    net32 = make_net().eval()
 
     def patched(model):
         def _state_transition(self, x_t, v_t):  # same signature as mppi_differential_drive.py:182
@@ -371,6 +378,11 @@ def gen_config5():
         caps.pop("optimal_traj")
         save(name, kw, dict(x0=np.array(x0, float), eps_seed=np.array(seed), eps=eps if K <= 256 else None, **caps))
 
+    if TWO_LAYER:
+        tt = np.arange(25)
+        one("c5_mlp2l_k128", dd_main_kwargs(param_exploration=0.05, visualize_optimal_traj=False, visualze_sampled_trajs=False),
+            [0.4, -0.1, -0.35], 73, np.stack([1.2 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1), 2)
+        return
     tt = np.arange(25)
     one("c5_mlp_k128", dd_main_kwargs(param_exploration=0.05, visualize_optimal_traj=False, visualze_sampled_trajs=False),
         [0.4, -0.1, -0.35], 71, np.stack([1.2 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1), 2)
@@ -382,6 +394,8 @@ def gen_config5():
 
 if __name__ == "__main__" and "c5" in sys.argv[1:]:
     gen_config5()
+if __name__ == "__main__" and "c5two" in sys.argv[1:]:
+    gen_config5(TWO_LAYER=True)
 
 
 # ---------------------------------------------------------------------------------------

@@ -52,7 +52,9 @@ def make_racecar_oracle(fx, raise_at_path_end=False):
     return o
 
 
-def mlp_weights():
-    """saved_models/mlp_diff_300x100_3l.pth as plain arrays (the checkpoint itself stays in the build container)."""
-    z = np.load(os.path.join(GOLDEN, "mlp_diff_300x100_3l_weights.npz"), allow_pickle=False)
+def mlp_weights(fixture=""):
+    """saved_models/mlp_diff_300x100_3l.pth as plain arrays (the checkpoint itself stays in the build container); for the
+    fixtures named `..mlp2l..` the reference's older two-hidden-layer checkpoint mlp_diff_300x100.pth."""
+    name = "mlp_diff_300x100_weights.npz" if "mlp2l" in fixture else "mlp_diff_300x100_3l_weights.npz"
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return {k: z[k] for k in z.files}

@@ -735,7 +735,7 @@ def test_config5_checkpoint_against_patched_reference(monkeypatch, name, kernel)
     if kernel == "f32":
         monkeypatch.setenv("MPPI_MLP_F32", "1")
     fx = gu.load(name)
-    c = pkg.MPPIAlgorithms(**fx["meta"], learned_dynamics=gu.mlp_weights())
+    c = pkg.MPPIAlgorithms(**fx["meta"], learned_dynamics=gu.mlp_weights(name))
     c.u_prev[:] = fx["u_prev_in"]
     c.prev_way_point_idx = int(fx["idx_before"])
     eps = gu.eps_of(fx)

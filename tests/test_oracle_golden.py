@@ -136,7 +136,7 @@ def test_config5_residual_mlp_matches_patched_reference(name):
     x + dt (f + MLP) (the reference's MultiLayerPerceptron with saved_models/mlp_diff_300x100_3l.pth, f64), see
     oracle/gen_golden.py gen_config5.  The restatement = DiffDriveMlpOracle with the same weights."""
     fx = gu.load(name)
-    w = gu.mlp_weights()
+    w = gu.mlp_weights(name)  # (`..mlp2l..`: the reference's older two-hidden-layer checkpoint)
     o = mppi_oracle.DiffDriveMlpOracle(**fx["meta"], mlp_weights=w)
     o.u_prev[:] = fx["u_prev_in"]
     o.prev_way_point_idx = int(fx["idx_before"])

@@ -1,14 +1,18 @@
-"""Copy the measurements of one `tools/make_profiles.sh <round>` run (gpurun_out/prof_<round>/) into profiles/ and derive
-the counter summaries bench.py quotes -- each stamped with the identity of the kernel sources it was taken with
-(`build_id` = dnn_mppi_mpc_amd.source_id(); the bench line of the same run carries it in config.build_id and must agree).
+"""Summaries of one `tools/make_profiles.sh <round>` run (gpurun_out/prof_<round>/), each stamped with the identity of the
+kernel sources it was taken with (`build_id` = dnn_mppi_mpc_amd.source_id(); the bench lines of the same run carry it in
+config.build_id and must agree).
 
-  <round>_pmc_valu.json     instructions per wave (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_INSTS_LDS over SQ_WAVES) and the VALU
-                            issue time they imply: per wave x waves per SIMD x 4 clocks (a wave64 VALU instruction
-                            occupies the SIMD16 for 4 clocks; quarter-rate instructions take longer: a LOWER bound)
-  <round>_pmc_traffic.json  HBM bytes per launch per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
-                            (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for wide coalesced streams on gfx950 (FETCH_SIZE counts
-                            a 128-byte read request as 64 B); raw and corrected values both stored
-usage: python tools/collect_profiles.py r02
+  --on-box   (called by make_profiles.sh on the GPU box) the reduced counter rows of every PMC pass ->
+             gpurun_out/prof_<round>/pmc.json AND profiles/<round>_pmc.json, so that the bench lines taken afterwards quote
+             the counter figures of their own build
+  (default)  in the build container: copy the run's files into profiles/<round>_*
+
+<round>_pmc.json: {"build_id", "kernels": [{"kernel" (as rocprofv3 prints it), "grid", "wg" (work-items), "vgprs", "sgprs",
+"lds", "launches_averaged", "counters": {name: mean per launch}}]} -- one entry per kernel instantiation AND launch size;
+bench.py looks an entry up by the instantiation its timed launches took (mppi_get_rollout_kernel) and the launch's workgroup
+count, and quotes nothing when there is none.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts a
+wide coalesced read at half its bytes, /opt/skills/guides/MI355X_MICROARCH.md, HBM section), applied where it is quoted.
+usage: python tools/collect_profiles.py r03 [--on-box]
 """
 import csv
 import glob
@@ -19,10 +23,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
+ON_BOX = "--on-box" in sys.argv
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
-GHZ = 2.07  # shader clock while these kernels run (clock64 against the wall clock, round 1 stamps build)
 
 
 def build_id():
@@ -32,84 +36,60 @@ def build_id():
     return m.source_id()
 
 
-def reduced(name):
-    p = os.path.join(SRC, name + ".reduced.csv")
-    return list(csv.DictReader(open(p))) if os.path.exists(p) else []
-
-
-def counters(rows, kern):
-    out, n = {}, 0
-    for r in rows:
-        if kern in r["Kernel_Name"]:
-            out[r["Counter_Name"]] = float(r["Mean_Value"])
+def pmc_json():
+    entries = {}
+    for path in sorted(glob.glob(os.path.join(SRC, "pmc_*.reduced.csv"))):
+        for r in csv.DictReader(open(path)):
+            if "mppi::" not in r["Kernel_Name"]:
+                continue
+            key = (r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            e = entries.setdefault(key, {"kernel": r["Kernel_Name"], "grid": key[1], "wg": key[2], "vgprs": int(r["VGPR_Count"]),
+                                         "sgprs": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "launches_averaged": 0,
+                                         "counters": {}, "counter_launches": {}, "passes": []})
             n = int(r["Launches_Averaged"])
-            out["_kernel"] = r["Kernel_Name"]
-            out["_vgpr"], out["_sgpr"], out["_lds"] = int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["LDS_Block_Size"])
-    return out, n
+            # (the same counter from two passes -- SQ_WAVES rides along in several --: the pass with more launches)
+            if n >= e["counter_launches"].get(r["Counter_Name"], -1):
+                e["counters"][r["Counter_Name"]] = float(r["Mean_Value"])
+                e["counter_launches"][r["Counter_Name"]] = n
+            e["launches_averaged"] = max(e["launches_averaged"], n)
+            tag = os.path.basename(path)[:-len(".reduced.csv")]
+            if tag not in e["passes"]:
+                e["passes"].append(tag)
+    return {"build_id": build_id(),
+            "_note": "rocprofv3 --pmc passes of the bench commands (tools/make_profiles.sh), one run per counter set, --kernel-trace "
+                     "only; per kernel instantiation and launch size: mean per launch after dropping the first quarter of the "
+                     "launches (tools/pmc_reduce.py).  FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (uncorrected)",
+            "kernels": sorted(entries.values(), key=lambda e: (e["kernel"], e["grid"]))}
 
 
-def valu_entry(rows, kern):
-    c, n = counters(rows, kern)
-    if not c:
-        return None
-    waves = c["SQ_WAVES"]
-    per_wave = {"VALU": c["SQ_INSTS_VALU"] / waves, "SALU": c["SQ_INSTS_SALU"] / waves, "LDS": c["SQ_INSTS_LDS"] / waves}
-    wps = max(1, round(waves / 1024.0))  # 256 compute units x 4 SIMDs
-    clocks = per_wave["VALU"] * wps * 4.0
-    return {"kernel": c["_kernel"], "launches_averaged": n, "waves": waves, "per_wave": per_wave, "waves_per_simd": wps,
-            "vgprs": c["_vgpr"], "sgprs": c["_sgpr"], "lds_bytes_per_workgroup": c["_lds"],
-            "valu_issue_clocks_per_simd": clocks, "shader_clock_GHz_in_kernel": GHZ, "valu_issue_us": clocks / GHZ * 1e-3}
-
-
-def copy(src_glob, dst_name):
-    hits = sorted(glob.glob(os.path.join(SRC, src_glob), recursive=True), key=os.path.getmtime)
-    if hits:  # (gpurun_out/ accumulates over calls: the newest)
-        shutil.copy(hits[-1], os.path.join(DST, f"{R}_{dst_name}"))
-        return True
-    print("missing", src_glob)
-    return False
-
+if ON_BOX:
+    d = pmc_json()
+    json.dump(d, open(os.path.join(SRC, "pmc.json"), "w"), indent=1)
+    shutil.copy(os.path.join(SRC, "pmc.json"), os.path.join(DST, f"{R}_pmc.json"))
+    print(f"{len(d['kernels'])} (kernel, launch size) entries, build {d['build_id']}")
+    sys.exit(0)
 
 bid = build_id()
-bench = json.load(open(os.path.join(SRC, "bench.json")))
-if bench["config"]["build_id"] != bid:
-    raise SystemExit(f"the profiles were taken with build {bench['config']['build_id']}, the tree is {bid}: run make_profiles.sh again")
-for f in ("bench.json", "bench_steps20.json", "bench_c3.json", "bench_c4.json", "bench_c5.json", "configs.jsonl"):
-    copy(f, f)
-if os.path.exists(os.path.join(ROOT, "gpurun_out", "issue_cost.txt")):  # tools/issue_cost.hip, when it was run this round
-    shutil.copy(os.path.join(ROOT, "gpurun_out", "issue_cost.txt"), os.path.join(DST, f"{R}_issue_cost.txt"))
-copy("kt/**/*kernel_stats.csv", "kernel_stats.csv")
-copy("kt_trav/**/*kernel_stats.csv", "traversal_kernel_stats.csv")
-copy("kt_cfg/**/*kernel_stats.csv", "configs34_kernel_stats.csv")
-for d in ("pmc_inst", "pmc_fetch", "pmc_write", "pmc_trav", "pmc_cfg4"):
-    copy(d + ".reduced.csv", d + ".csv")
-
-valu = {"build_id": bid,
-        "_note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace (its own run each: "
-                 "tools/make_profiles.sh); valu_issue = instructions per wave x waves per SIMD x 4 clocks: an instruction-count "
-                 "MODEL of the VALU pipe's busy time, not a bound -- measured issue costs at four waves per SIMD "
-                 "(tools/issue_cost.hip, profiles/*_issue_cost.txt): 2.5 cycles for plain f32 / integer / logic operations on "
-                 "VGPR or literal operands, 4.3 for DPP, compares, min/max, conversions, integer multiplies (v_mad_u64_u32 "
-                 "included), packed f32 and ANY instruction with an SGPR operand, 8.3 for transcendentals"}
-for label, rows, kern in (
-        ("config 2: lean rollout kernel (the hold phase and every launch of the frozen index)", reduced("pmc_inst"), "k_rollout_fused<float, 0, 1, false, 2, false>"),
-        ("config 2 traversal: rollout kernel that resolves the sequential index in one launch", reduced("pmc_trav"), "k_rollout_fused<float, 0, 1, false, 2, true>"),
-        ("config 2 traversal: k_finalize with the map composition", reduced("pmc_trav"), "k_finalize<float, 0, 1, false, true, true>"),
-        ("config 2: k_finalize (lean)", reduced("pmc_inst"), "k_finalize<float, 0, 1, false, true, false>"),
-        ("config 4 shard: k_rollout_dual<float, racecar, 1 sample per wave, 2 in sequence>, K=8192 T=75", reduced("pmc_cfg4"), "k_rollout_dual<float, 1, 1, false, 2")):
-    e = valu_entry(rows, kern)
-    if e:
-        valu[label] = e
-json.dump(valu, open(os.path.join(DST, f"{R}_pmc_valu.json"), "w"), indent=1)
-
-fetch, nf = counters(reduced("pmc_fetch"), "k_rollout_fused<float, 0, 1, false, 2, false>")
-write, nw = counters(reduced("pmc_write"), "k_rollout_fused<float, 0, 1, false, 2, false>")
-if fetch and write:
-    traffic = {"build_id": bid, "kernel": fetch["_kernel"], "launches_averaged": [nf, nw],
-               "FETCH_SIZE_raw_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_raw_KB": write["WRITE_SIZE"],
-               "correction": "gfx950: FETCH_SIZE reads half of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM); "
-                             "WRITE_SIZE exact",
-               "hbm_bytes_per_launch": (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0}
-    json.dump(traffic, open(os.path.join(DST, f"{R}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: (v if not isinstance(v, dict) else {"VALU": v["per_wave"]["VALU"], "issue_us": v["valu_issue_us"]})
-                  for k, v in valu.items() if k != "_note"}, indent=1))
+pmc = json.load(open(os.path.join(SRC, "pmc.json")))
+if pmc["build_id"] != bid:
+    raise SystemExit(f"the profiles were taken with build {pmc['build_id']}, the tree is {bid}: run make_profiles.sh again")
+for f in sorted(glob.glob(os.path.join(SRC, "bench*.json"))):
+    line = open(f).read().strip().splitlines()
+    if not line:
+        print("empty", f)
+        continue
+    d = json.loads(line[-1])
+    got = d.get("config", {}).get("build_id")
+    if got != bid:
+        raise SystemExit(f"{f} is of build {got}, the tree is {bid}")
+    shutil.copy(f, os.path.join(DST, f"{R}_{os.path.basename(f)}"))
+shutil.copy(os.path.join(SRC, "pmc.json"), os.path.join(DST, f"{R}_pmc.json"))
+for f in sorted(glob.glob(os.path.join(SRC, "kernel_stats_*.csv"))) + sorted(glob.glob(os.path.join(SRC, "pmc_*.reduced.csv"))):
+    shutil.copy(f, os.path.join(DST, f"{R}_{os.path.basename(f).replace('.reduced', '')}"))
+if os.path.exists(os.path.join(SRC, "parity_margins.txt")):
+    shutil.copy(os.path.join(SRC, "parity_margins.txt"), os.path.join(DST, f"{R}_parity_margins.txt"))
+print("copied; build", bid)
+for e in pmc["kernels"]:
+    c = e["counters"]
+    if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
+        print("%-100s wgs %6d  VALU/wave %7.1f  launches %d" % (e["kernel"][:100], e["grid"] // e["wg"], c["SQ_INSTS_VALU"] / c["SQ_WAVES"], e["launches_averaged"]))

@@ -1,39 +1,72 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/make_profiles.sh r02'): every measurement profiles/ holds for one build.
-# rocprofv3 passes are separate runs: --kernel-trace --stats for durations; --pmc passes (their own runs, --kernel-trace
-# only) for HBM traffic and instruction counts.  Output: gpurun_out/prof_<round>/ ; tools/collect_profiles.py copies the
-# summaries into profiles/ afterwards (in the build container).
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/make_profiles.sh r03'): every measurement profiles/ holds for one build.
+#   1. rocprofv3 --kernel-trace --stats of every bench command (durations, launch counts)
+#   2. rocprofv3 --pmc passes, each its own run with --kernel-trace only (instruction counts; FETCH_SIZE; WRITE_SIZE; the
+#      matrix-pipe counters of the learned-dynamics kernel), reduced to one row per (kernel, launch size, counter)
+#   3. tools/collect_profiles.py <round> --on-box: the reduced rows -> gpurun_out/prof_<round>/pmc.json, copied to
+#      profiles/<round>_pmc.json ON THE BOX so that
+#   4. the bench lines taken last quote the counter figures of their own build (same sources = same build id).
+# Output: gpurun_out/prof_<round>/ ; `python tools/collect_profiles.py <round>` (build container) copies it into profiles/.
 set -o pipefail
-R=${1:-r02}
-OUT=gpurun_out/prof_$R
-mkdir -p $OUT
+R=${1:-r03}
+OUT="gpurun_out/prof_${R}"
+mkdir -p "$OUT"
+find "$OUT" -mindepth 1 -delete
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# (the profiler passes time the headline path alone: --no-batched leaves the 32-agent block of the default line out)
-BENCH="bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-batched --no-graph-timing"
-echo "== bench lines"; date
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
-timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_steps20.json 2>> $OUT/bench.err || echo "bench20 failed"
-echo "== kernel trace of the bench command"; date
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $BENCH > $OUT/kt.log 2>&1 || echo "kt failed"
-echo "== PMC: instruction counts"; date
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_inst -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_inst.log 2>&1 || echo "pmc_inst failed"
-echo "== PMC: HBM traffic"; date
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-batched --no-graph-timing > $OUT/pmc_write.log 2>&1 || echo "pmc_write failed"
-echo "== traversal only (HYPK kernels)"; date
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_trav -- python3 tools/traverse_only.py 100 > $OUT/kt_trav.log 2>&1 || echo "kt_trav failed"
-timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_trav -- python3 tools/traverse_only.py 20 > $OUT/pmc_trav.log 2>&1 || echo "pmc_trav failed"
-echo "== other configs"; date
-timeout -k 10 400 python3 tools/bench_configs.py 3 4s 4 5 > $OUT/configs.jsonl 2> $OUT/configs.err || echo "configs failed"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_cfg -- python3 tools/bench_configs.py 3 4s > $OUT/kt_cfg.log 2>&1 || echo "kt_cfg failed"
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_cfg4 -- python3 tools/bench_configs.py 4s > $OUT/pmc_cfg4.log 2>&1 || echo "pmc_cfg4 failed"
-timeout -k 10 300 python3 bench.py --workload c4 --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err || echo "bench c4 failed"
-# keep what travels back small: counter CSVs are large
-for d in pmc_inst pmc_fetch pmc_write pmc_trav pmc_cfg4; do
-  f=$(find $OUT/$d -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 tools/pmc_reduce.py "$f" $OUT/$d.reduced.csv && rm -rf $OUT/$d
+Q="--no-cpu-baseline --no-batched --no-graph-timing"
+declare -A CMD
+CMD[c2]="bench.py --steps 2000 --warmup 200 $Q"
+CMD[c3]="bench.py --workload c3 --steps 600 --warmup 60 $Q"
+CMD[c4]="bench.py --workload c4 --steps 200 --warmup 20 $Q"
+CMD[c5]="bench.py --workload c5 --steps 12 --warmup 2 $Q"
+CMD[eps_c2]="bench.py --eps hbm --workload c2 --steps 200 --warmup 20"
+CMD[eps_c4]="bench.py --eps hbm --workload c4 --steps 100 --warmup 10"
+CMD[trav]="tools/traverse_only.py 60"
+reduce() {  # <pass name>: the pass's counter CSV -> <pass name>.reduced.csv; the raw output (large) is dropped
+  local d="$OUT/$1"
+  local f
+  f=$(find "$d" -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 tools/pmc_reduce.py "$f" "$d.reduced.csv"
+  find "$d" -mindepth 1 -delete; rmdir "$d"
+}
+echo "== kernel traces"; date
+for W in c2 c3 c4 c5 eps_c2 eps_c4 trav; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$W" -- python3 ${CMD[$W]} > "$OUT/kt_$W.log" 2>&1 || echo "kt $W failed"
+  f=$(find "$OUT/kt_$W" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$W.csv"
+  find "$OUT/kt_$W" -mindepth 1 -delete; rmdir "$OUT/kt_$W"
 done
-find $OUT -name "*_kernel_trace.csv" -delete
-find $OUT -name "*agent_info.csv" -delete
-du -sh $OUT; ls $OUT
+echo "== PMC: instruction counts"; date
+for W in c2 c3 c4 eps_c2 eps_c4 trav; do
+  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_inst_$W" -- python3 ${CMD[$W]} > "$OUT/pmc_inst_$W.log" 2>&1 || echo "pmc_inst $W failed"
+  reduce "pmc_inst_$W"
+done
+echo "== PMC: HBM traffic"; date
+for W in c2 c3 c4 eps_c2 eps_c4; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$W" -- python3 ${CMD[$W]} > "$OUT/pmc_${C}_$W.log" 2>&1 || echo "pmc $C $W failed"
+    reduce "pmc_${C}_$W"
+  done
+done
+echo "== PMC: matrix pipe of the learned-dynamics kernel"; date
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d "$OUT/pmc_mfma_c5" -- python3 ${CMD[c5]} > "$OUT/pmc_mfma_c5.log" 2>&1 || echo "pmc_mfma failed"
+reduce pmc_mfma_c5
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$OUT/pmc_mfma2_c5" -- python3 ${CMD[c5]} > "$OUT/pmc_mfma2_c5.log" 2>&1 || echo "pmc_mfma2 failed"
+reduce pmc_mfma2_c5
+echo "== counter summaries -> profiles/${R}_pmc.json (on the box: the bench lines below quote them)"; date
+python3 tools/collect_profiles.py "$R" --on-box || echo "collect failed"
+echo "== bench lines"; date
+timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed"
+timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_steps20.json" 2>> "$OUT/bench.err" || echo "bench20 failed"
+timeout -k 10 300 python3 bench.py --workload c3 --steps 1000 --warmup 100 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err" || echo "bench c3 failed"
+timeout -k 10 300 python3 bench.py --workload c4 --steps 300 --warmup 30 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err" || echo "bench c4 failed"
+timeout -k 10 300 python3 bench.py --workload c5 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || echo "bench c5 failed"
+timeout -k 10 300 python3 bench.py --eps hbm --workload c2 > "$OUT/bench_eps_c2.json" 2> "$OUT/bench_eps_c2.err" || echo "bench eps c2 failed"
+timeout -k 10 300 python3 bench.py --eps hbm --workload c4 > "$OUT/bench_eps_c4.json" 2> "$OUT/bench_eps_c4.err" || echo "bench eps c4 failed"
+echo "== self-launched 2-rank rehearsals (one GPU, gloo host side)"; date
+for W in c2 c4; do
+  MPPI_BENCH_DEVICE=0 MPPI_BENCH_BACKEND=gloo timeout -k 10 300 python3 bench.py --gpus 2 --workload $W --steps 200 --warmup 20 > "$OUT/bench_2rank_$W.json" 2> "$OUT/bench_2rank_$W.err" || echo "2-rank $W failed"
+done
+echo "== parity margins"; date
+timeout -k 10 300 python3 -m pytest tests -m gpu -q -s -k "config5_checkpoint" 2>&1 | grep PARITY_MARGIN > "$OUT/parity_margins.txt"
+du -sh "$OUT"; ls "$OUT"
 date
