@@ -10,7 +10,8 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ABI_VERSION = 4  # MPPI_ABI_VERSION of include/mppi_hip.h this mirror was written against
-MIN_AB_ABI_VERSION = 3  # oldest library an MPPI_LIB override may point at: same mppi_config / mppi_stats layouts as now
+MIN_AB_ABI_VERSION = 3  # oldest library an MPPI_LIB override may point at: same mppi_config layout as now (an ABI-3 library
+                        # fills the first fields of mppi_stats only: the struct grew at its end in version 4)
 LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.so")  # MPPI_LIB: A/B a diagnostic build
 
 # enums of mppi_hip.h
@@ -43,7 +44,8 @@ class MppiConfig(C.Structure):
 
 class MppiStats(C.Structure):
     _fields_ = [("rho", C.c_double), ("eta", C.c_double), ("ess", C.c_double), ("idx_start", C.c_int32),
-                ("idx_after", C.c_int32), ("path_end", C.c_int32), ("rounds", C.c_int32), ("iteration", C.c_int64)]
+                ("idx_after", C.c_int32), ("path_end", C.c_int32), ("rounds", C.c_int32), ("iteration", C.c_int64),
+                ("n_collided", C.c_int32), ("reserved", C.c_int32), ("iter_us", C.c_double), ("kernel_us", C.c_double)]
 
 
 class MppiError(RuntimeError):

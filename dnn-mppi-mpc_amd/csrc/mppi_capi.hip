@@ -70,6 +70,7 @@ struct mppi_handle {
     size_t ev_used = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
+    double last_iter_us = 0.0;  // host wall time per iteration of the last step / closed-loop call (mppi_stats::iter_us)
     // peer-to-peer exchange (mppi_comm_*)
     char *xbuf = nullptr;            // this rank's exchange buffer (fine-grained device memory)
     size_t xbuf_bytes = 0;
@@ -809,6 +810,10 @@ static void fill_stats(const mppi_handle *h, mppi_stats *stats) {
     stats->path_end = r->path_end;
     stats->rounds = r->rounds;
     stats->iteration = r->iter;
+    stats->n_collided = r->n_collided;
+    stats->reserved = 0;
+    stats->iter_us = h->last_iter_us;
+    stats->kernel_us = h->timing ? 1e3 * ((double)h->last_ms[0] + h->last_ms[1] + h->last_ms[2]) : 0.0;
 }
 
 // The x0 call (mppi_differential_drive.py:96-99 / mppi_race_car.py:61): nearest waypoint of the observed state
@@ -865,6 +870,7 @@ template <typename R>
 static int step_impl(mppi_handle *h, const double *x0, const double *x0_dev, const float *eps, double *u_out, double *u0_out,
                      mppi_stats *stats, hipStream_t s) {
     if (h->rccl_comm && h->x_nranks <= 1) return step_rccl<R>(h, x0, x0_dev, eps, u_out, u0_out, stats, s);
+    const double t_call = now_s();
     KParams<R> P = make_params<R>(h, eps);
     FinalizeParams F = make_finalize(h, h->d_partials, h->n_part, 0);
     const bool by_args = x0 && h->idx_valid && h->by_args_ok;
@@ -895,6 +901,7 @@ static int step_impl(mppi_handle *h, const double *x0, const double *x0_dev, con
     h->last_philox = eps == nullptr;
     h->idx = h->h_res->idx_after;
     h->idx_valid = true;
+    h->last_iter_us = 1e6 * (now_s() - t_call);
     fill_stats(h, stats);
     if (h->h_res->status == STATUS_EXCHANGE_FAILED)
         FAIL(h, MPPI_ERR_COMM, "peer-to-peer exchange: a rank did not arrive within the timeout");
@@ -1608,6 +1615,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         if (++guard > h->cfg.K + 64) FAIL(h, MPPI_ERR_STATE, "closed loop did not make progress");
     }
     h->t_loop_s += now_s() - t_call;
+    h->last_iter_us = 1e6 * (now_s() - t_call) / (n_iters > 0 ? n_iters : 1);
     h->last_eps = nullptr;
     h->last_philox = true;
     h->idx = h->h_res->idx_after;

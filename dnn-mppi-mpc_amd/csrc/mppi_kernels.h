@@ -51,6 +51,7 @@ struct StepResult {
     int status, k_next, c_next, idx_start;
     int idx_after, path_end, rounds;
     int costs_hyp;  // the iteration ended in the one-launch resolution: S[k] = hyp_S[k / 16][hyp_q[k / 16]][k % 16]
+    int n_collided, pad_res;  // samples of this handle whose cost carries a collision penalty (-1: records of other ranks merged)
     long long iter;
     double rho, eta, ess;
     double u0[2];

@@ -473,18 +473,19 @@ __device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &s
     }
     if (lane < HYP_R) P.hyp_S[(b * HYP_R + lane) * FUSED_WAVES + wid] = SQ;
     if (wid == FUSED_WAVES - 1 && lane < HYP_R) {
-        R eta = 0, eta2 = 0;
+        R eta = 0, eta2 = 0, n_hit = 0;
 #pragma unroll
         for (int w = 0; w < FUSED_WAVES; ++w) {
             const R ew = sh_e[w][lane];
             eta += ew;
             eta2 += ew * ew;
+            if (OBS) n_hit += (sh_SQ[w][lane] >= P.penalty && sh_SQ[w][lane] < R(INFINITY)) ? R(1) : R(0);
         }
         R *out = P.hyp_rec + (b * HYP_R + lane) * rlen;
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.hyp_heads + 4 * (b * HYP_R + lane)) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.hyp_heads + 4 * (b * HYP_R + lane)) = VecT4<R>{rho, eta, eta2, n_hit};
         P.hyp_map[b * HYP_R + lane] = (unsigned char)after;
     }
 }
@@ -577,17 +578,19 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         out[4 + i] = s;
     }
     if (threadIdx.x == 64 * (FUSED_WAVES - 1)) {  // a lane of the last wave: the first ones carry the column sums
-        R eta = 0, eta2 = 0;
+        // (the head's fourth word: how many of the workgroup's samples carry a collision penalty in their cost -- mppi_stats::n_collided)
+        R eta = 0, eta2 = 0, n_hit = 0;
 #pragma unroll
         for (int w = 0; w < FUSED_WAVES; ++w) {
             const R ew = sh_e[w];
             eta += ew;
             eta2 += ew * ew;
+            if (OBS) n_hit += (sh_S[w] >= P.penalty && sh_S[w] < R(INFINITY)) ? R(1) : R(0);
         }
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, n_hit};
         if (seq_search) publish_first_mover<FUSED_WAVES>(sh_mover, &(P.st + agent)->first_k);
     }
     STAMP(4);
@@ -938,17 +941,19 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
         out[4 + i] = acc;
     }
     if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
-        R eta = 0, eta2 = 0;
+        R eta = 0, eta2 = 0, n_hit = 0;
+        const bool count_hits = P.obstacle_model != OBS_NONE;
 #pragma unroll
         for (int q = 0; q < SAMPLES; ++q) {
             const R ew = sh_e[q];
             eta += ew;
             eta2 += ew * ew;
+            if (count_hits) n_hit += (sh_S[q] >= P.penalty && sh_S[q] < R(INFINITY)) ? R(1) : R(0);
         }
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, n_hit};
         if (seq_search) publish_first_mover<ROWS>(sh_mover, &(P.st + agent)->first_k);
     }
     STAMP(4);
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
     const R *__restrict__ u_ = P.u + (size_t)agent * 2 * P.T;
     R *__restrict__ S_ = P.S + (size_t)agent * P.K;
     __shared__ R sh_rho[ROWS];
-    __shared__ R sh_eta[ROWS][2];
+    __shared__ R sh_eta[ROWS][3];
     __shared__ __attribute__((aligned(16))) R sh_acc[ROWS][128];
     __shared__ __attribute__((aligned(16))) float sh_raw[ROWS][128];
     __shared__ __attribute__((aligned(16))) R sh_u[128];
@@ -1033,6 +1038,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
     const R ca = wv::read_lane(u_la * P.sinv[0] + u_lb * P.sinv[2], 0), cb = wv::read_lane(u_la * P.sinv[1] + u_lb * P.sinv[3], 0);
     // this half-wave's private record (rho, eta, eta2 uniform within the half; w*: this lane's four columns)
     R rho_h = R(INFINITY), eta_h = R(0), eta2_h = R(0), w0 = R(0), w1 = R(0), w2 = R(0), w3 = R(0);
+    R hit_h = R(0);  // samples of this half-wave whose cost carries a collision penalty
     for (int pass = 0; pass < n_pass; ++pass) {
         const int batch = b0 + pass;
         if (batch >= n_batch) break;  // (uniform over the workgroup)
@@ -1108,6 +1114,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
         if (hit) term += P.penalty;
         const R S_k = (st_c + P.gamma * ctrl) + term;
         if (l32 == 0 && valid) S_[k] = S_k;
+        if (OBS && valid && hit) hit_h += R(1);
         if (valid) {  // (uniform within the half) merge the sample into the half-wave's record
             const R rho_new = fmin(rho_h, S_k);
             const R scale = rho_h < R(INFINITY) ? mf::exp_(-P.beta * (rho_h - rho_new)) : R(0);
@@ -1125,7 +1132,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
     __syncthreads();
     const R rho = wv::read_lane(wv::scan_incl_half<wv::OpMin>(sh_rho[l32]), 31);
     const R sc = rho_h < R(INFINITY) ? mf::exp_(-P.beta * (rho_h - rho)) : R(0);
-    if (l32 == 0) { sh_eta[sidx][0] = sc * eta_h; sh_eta[sidx][1] = sc * sc * eta2_h; }
+    if (l32 == 0) { sh_eta[sidx][0] = sc * eta_h; sh_eta[sidx][1] = sc * sc * eta2_h; sh_eta[sidx][2] = hit_h; }
     *reinterpret_cast<VecT4<R> *>(&sh_acc[sidx][4 * l32]) = VecT4<R>{sc * w0, sc * w1, sc * w2, sc * w3};
     __syncthreads();
     const size_t slot = (size_t)agent * P.slots + blockIdx.x;  // this workgroup's record
@@ -1137,13 +1144,13 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, sizeof(R) == 4 ? 8 : 1) void k_rol
         out[4 + tid] = acc;
     }
     if (tid == 64 * (DUAL_WAVES - 1)) {
-        R eta = 0, eta2 = 0;
+        R eta = 0, eta2 = 0, n_hit = 0;
 #pragma unroll
-        for (int q = 0; q < ROWS; ++q) { eta += sh_eta[q][0]; eta2 += sh_eta[q][1]; }
+        for (int q = 0; q < ROWS; ++q) { eta += sh_eta[q][0]; eta2 += sh_eta[q][1]; n_hit += sh_eta[q][2]; }
         out[0] = rho;
         out[1] = eta;
         out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) = VecT4<R>{rho, eta, eta2, n_hit};
     }
 }
 
@@ -1171,25 +1178,27 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
     for (int w = 1; w < nw; ++w) rho = fmin(rho, sh_red[w]);
     __syncthreads();
 
-    R eta = 0, eta2 = 0;
+    R eta = 0, eta2 = 0, n_hit = 0;
     for (int i = tid; i < nk; i += blockDim.x) {
         const R e = mf::exp_(-P.beta * (P.S[k0 + i] - rho));  // :175
         sh_e[i] = e;
         eta += e;
         eta2 += e * e;
+        if (P.obstacle_model != OBS_NONE && P.S[k0 + i] >= P.penalty) n_hit += R(1);
     }
     eta = wv::reduce<wv::OpAdd>(eta);
     eta2 = wv::reduce<wv::OpAdd>(eta2);
-    if (lane == 0) { sh_red[4 + wid] = eta; sh_red[8 + wid] = eta2; }
+    n_hit = wv::reduce<wv::OpAdd>(n_hit);
+    if (lane == 0) { sh_red[4 + wid] = eta; sh_red[8 + wid] = eta2; sh_red[12 + wid] = n_hit; }
     __syncthreads();
     R *out = partials + (size_t)blockIdx.x * record_len(P.T, (int)sizeof(R));
     if (tid == 0) {
-        R a = 0, b = 0;
-        for (int w = 0; w < nw; ++w) { a += sh_red[4 + w]; b += sh_red[8 + w]; }
+        R a = 0, b = 0, nh = 0;
+        for (int w = 0; w < nw; ++w) { a += sh_red[4 + w]; b += sh_red[8 + w]; nh += sh_red[12 + w]; }
         out[0] = rho;
         out[1] = a;
         out[2] = b;
-        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, a, b, R(0)};
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * (size_t)blockIdx.x) = VecT4<R>{rho, a, b, nh};
     }
 
     // W_b[t] = sum_k e_k eps[k, t]  (:132-135 with the 1/eta factored out), lanes over t
@@ -1361,6 +1370,7 @@ template <typename A> struct BlockRed {  // block-wide reductions through one LD
 template <typename A, int NT = MERGE_THREADS, int NWIN = 1> struct MergeRegs {
     VecT<A> w[NWIN][MergeShape<NT>::MAXJ];
     A hr[4 * NWIN], he[4 * NWIN], he2[4 * NWIN];  // heads of records 256 win + lane + {0, 64, 128, 192}
+    A hc[4 * NWIN];                                // their fourth word: samples that carry a collision penalty
 };
 
 // `sel` (LDS, one byte per record): record b is entry sel[b] of workgroup b's HYP_R records (fused_hyp) -- the stride
@@ -1377,6 +1387,7 @@ __device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, Me
         m.hr[i] = hd.x;
         m.he[i] = hd.y;
         m.he2[i] = hd.z;
+        m.hc[i] = hd.w;
     }
 }
 
@@ -1410,7 +1421,7 @@ __device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int 
 template <typename A, int NT, int NWIN, typename Store>
 __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta,
                                               MergeRegs<A, NT, NWIN> &m, A *sh_s, A *sh_part, A &rho, A &eta, A &eta2,
-                                              Store store, const unsigned char *sel = nullptr) {
+                                              Store store, const unsigned char *sel = nullptr, A *n_hit = nullptr) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ, GROUPS = MergeShape<NT>::GROUPS;
     using V = VecT<A>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1435,6 +1446,12 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
     }
     eta = wv::reduce<wv::OpAdd>(eta);
     eta2 = wv::reduce<wv::OpAdd>(eta2);
+    if (n_hit) {
+        A cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * NWIN; ++i) cnt += lane + 64 * i < n ? m.hc[i] : A(0);
+        *n_hit = wv::reduce<wv::OpAdd>(cnt);
+    }
     // this wave's two groups use the scales of records r0 .. r0 + 2 MAXJ - 1 only (a run inside one of the four
     // 64-record slots every lane holds): a wave-local exchange through 64 private LDS words, no block barrier
     // (per window)
@@ -1520,8 +1537,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     MergeRegs<A, MERGE_THREADS, 1> mr;
     merge_load_heads<A, MERGE_THREADS, 1>(heads + 4 * (size_t)b0, mr);
     merge_load_tile<A, MERGE_THREADS, 1>(mine, T, 0, mr);
-    A rho, eta, eta2;
-    merge_combine<A, MERGE_THREADS, 1>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; });
+    A rho, eta, eta2, n_hit = 0;
+    merge_combine<A, MERGE_THREADS, 1>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; }, nullptr, &n_hit);
     // merge_combine leaves W / eta; a record carries W itself
     if (ABI_OUT) {
         double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
@@ -1532,7 +1549,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
         for (int i = threadIdx.x; i < 2 * T; i += MERGE_THREADS) o[4 + i] = sh_w[i] * eta;
         if (threadIdx.x == 0) {
             o[0] = rho; o[1] = eta; o[2] = eta2;
-            *reinterpret_cast<VecT4<A> *>(out_heads + 4 * (size_t)blockIdx.x) = VecT4<A>{rho, eta, eta2, A(0)};
+            *reinterpret_cast<VecT4<A> *>(out_heads + 4 * (size_t)blockIdx.x) = VecT4<A>{rho, eta, eta2, n_hit};
         }
     }
 }
@@ -1816,12 +1833,13 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     const bool pad_copy = f_filter == FILTER_RACE || f_filter == FILTER_TORCH;
     auto store_w = [&](int i, A v) { filter_store<A>(sh_w, i, v, T, H, pad_copy); };
     A rho, eta, eta2;
+    A n_hit = A(-1);  // (-1: not known -- the records of other ranks carry no count)
     if (ABI_RECS) {
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
     } else if (!XCHG) {
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
-                                   eta, eta2, store_w, sel);
+                                   eta, eta2, store_w, sel, &n_hit);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
@@ -1920,6 +1938,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             res->path_end = path_end;
             res->rounds = round + 1;
             res->costs_hyp = hyp_done ? 1 : 0;
+            res->n_collided = (int)n_hit;
             res->rho = (double)rho; res->eta = (double)eta; res->ess = (double)(eta * eta / eta2);
             res->u0[0] = (double)u0a; res->u0[1] = (double)u0b;
             for (int q = 0; q < 4; ++q) res->x_next[q] = xn[q];

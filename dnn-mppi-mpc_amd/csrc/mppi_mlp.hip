@@ -242,11 +242,12 @@ __device__ __forceinline__ void mlp_record(const KParams<float> &P, float *__res
     const float rho = wv::reduce<wv::OpMin>(Sm);
     const float e = valid ? mf::exp_(-P.beta * (S - rho)) : 0.f;
     const float eta = wv::reduce<wv::OpAdd>(e), eta2 = wv::reduce<wv::OpAdd>(e * e);
+    const float n_hit = P.obstacle_model != OBS_NONE ? wv::reduce<wv::OpAdd>(valid && S >= P.penalty ? 1.f : 0.f) : 0.f;
     float *out = partials + (size_t)blockIdx.x * record_len(P.T, 4);
     if (lane == 0) {
         out[0] = rho; out[1] = eta; out[2] = eta2;
         float *hd = P.heads + 4 * (size_t)blockIdx.x;  // the compact copy the merge kernels read
-        hd[0] = rho; hd[1] = eta; hd[2] = eta2; hd[3] = 0.f;
+        hd[0] = rho; hd[1] = eta; hd[2] = eta2; hd[3] = n_hit;  // (n_hit: samples that carry a collision penalty)
     }
     for (int t = 0; t < P.T; ++t) {  // second pass over this tile's noise rows (regenerated / re-read)
         float e0 = 0.f, e1 = 0.f;

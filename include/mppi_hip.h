@@ -136,6 +136,15 @@ typedef struct {
     int32_t path_end;     /* idx_start reached the last waypoint (:97-99) */
     int32_t rounds;       /* speculation rounds the sequential waypoint mode needed (>= 1) */
     int64_t iteration;    /* iterations completed by this handle */
+    int32_t n_collided;   /* samples of the last iteration whose cost carries a collision penalty (`_is_collided`,
+                             _obs.py:301-313 / mppi_race_car_obstacle.py:255-274); 0 without obstacles; -1 when the records of
+                             other ranks were merged (K sharded: they carry no count) */
+    int32_t reserved;
+    double iter_us;       /* host wall time per iteration of the call that filled this struct (mppi_step: the call;
+                             mppi_run_closed_loop: the call divided by its iterations), microseconds */
+    double kernel_us;     /* rollout + merge + finalize kernel time per iteration by HIP events on the launch stream: the
+                             average over the last window of mppi_enable_timing, as of the last mppi_last_kernel_ms call;
+                             0 while timing is off */
 } mppi_stats;
 
 typedef struct mppi_handle mppi_handle;

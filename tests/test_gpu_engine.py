@@ -116,6 +116,39 @@ def test_config3_obstacles_k16384_against_c_oracle():
             assert np.mean((S > 1e9) != (ref["S"] > 1e9)) < 1e-3  # circle-boundary flips in f32
         assert rmse(u, ref["u_returned"]) <= tol
         assert c.prev_way_point_idx == ref["idx_after"]
+        # mppi_stats.n_collided: the samples whose cost carries a collision penalty, counted on the device
+        assert c.last_stats.n_collided == int(np.sum(S > 1e9)) > 0
+        assert c.last_stats.iter_us > 0.0
+
+
+def test_stats_collision_count_across_layouts():
+    """`mppi_stats.n_collided` through every record path: one sample per wave (K = 700), the index resolved in one launch
+    and by speculation rounds, two samples per wave (K = 9000), the streaming kernel (frozen), the race car's outline test,
+    the merge of > 512 records (K = 40000) and several agents; 0 without obstacles; the device closed loop reports the
+    last iteration's."""
+    import dnn_mppi_mpc_amd as pkg
+    circles = np.array([[1.0, -0.4, 0.3], [2.5, -1.4, 0.4]])
+    x0 = np.array([0.4, -0.1, -0.35])
+    for K, mode in ((700, None), (9000, None), (9000, "frozen"), (40000, "frozen")):
+        kw = dd_kwargs(K, 30, obstacle_circles=circles, safety_margin_rate=0.8, param_exploration=0.05)
+        c = pkg.MPPIAlgorithms(**kw, precision="f32", seed=3, **({} if mode is None else {"waypoint_mode": mode}))
+        tt = np.arange(30)
+        c.u_prev[:] = np.stack([2.0 + 0.3 * np.sin(0.2 * tt), 0.05 * np.cos(0.1 * tt)], axis=1)
+        c._calc_input_control(x0)
+        n = int(np.sum(c.sample_costs() > 1e9))
+        assert c.last_stats.n_collided == n and n > 0, (K, mode, c.last_stats.n_collided, n, c._engine.rollout_kernel())
+        c._engine.set_state(x0)
+        _, st = c._engine.run_closed_loop(3)
+        assert st.n_collided == int(np.sum(c._engine.costs() > 1e9))
+    c = pkg.MPPIAlgorithms(**dd_kwargs(700, 30), precision="f32", seed=3)
+    c._calc_input_control(x0)
+    assert c.last_stats.n_collided == 0
+    lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
+    rc = pkg.MPPIRacecarController(ref_path=lem, horizon_step_T=75, number_of_samples_K=3000, obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]),
+                                   visualize_optimal_traj=False, visualze_sampled_trajs=False, precision="f32", seed=5)
+    rc._calc_control_input(lem[0].astype(np.float64))  # (the driver's start: most samples cross a circle)
+    n = int(np.sum(rc.sample_costs() >= 1e10))
+    assert rc.last_stats.n_collided == n and n > 0
 
 
 def test_config4_racecar_k65536_shard_against_c_oracle():
