@@ -187,22 +187,23 @@ def host_cores():
 
 def cpu_baseline(budget_s=10.0, budget_all_s=6.0):
     """The C restatement of the reference loop (config 2, closed loop, eps pre-generated): the reference's own sequential
-    waypoint index on ONE host core (it cannot be parallelised over samples), and beside it the frozen-index variant
-    on all host cores (OpenMP over K) -- SURVEY.md section 8d-ii."""
+    waypoint index on ONE host core (it cannot be parallelised over samples), and beside it the per-rollout variant (the
+    index threads through each sample's own calls and restarts at every sample) on all host cores (OpenMP over K) --
+    SURVEY.md section 8d-ii."""
     from oracle import c_oracle, mppi_oracle, philox
     kw = config2_kwargs()
     pool = [philox.sample_epsilon(kw["sigma"], 1, i, K_SAMPLES, HORIZON) for i in range(4)]
 
     def run(budget, threads):
         o = c_oracle.DiffDriveC(**kw)
-        o.iteration(X_INIT.copy(), pool[0], frozen_threads=threads)  # warm the caches / start the thread team
+        o.iteration(X_INIT.copy(), pool[0], per_rollout_threads=threads)  # warm the caches / start the thread team
         n, spent, state = 0, 0.0, X_INIT.copy()
         while spent < budget:
             if n % EPISODE == 0:  # the same run as the GPU path times: a new episode of the driver every tSim iterations
                 o = c_oracle.DiffDriveC(**kw)
                 state = X_INIT.copy()
             t0 = time.perf_counter()
-            out = o.iteration(state, pool[n % len(pool)], frozen_threads=threads)
+            out = o.iteration(state, pool[n % len(pool)], per_rollout_threads=threads)
             spent += time.perf_counter() - t0
             state = mppi_oracle.diffdrive_plant_step(state, out["u0_returned"], kw["delta_t"])
             n += 1
@@ -219,8 +220,9 @@ def cpu_baseline(budget_s=10.0, budget_all_s=6.0):
             "ms_per_step": 1e3 * s1 / n1,
             "all_cores": {"value": K_SAMPLES * HORIZON * na / sa, "unit": "trajectory-steps/s", "cores": cores,
                           "ms_per_step": 1e3 * sa / na,
-                          "sample": f"{na} iterations of the same run in {sa:.1f} s with the FROZEN waypoint index "
-                                    "(samples independent), OpenMP over K on every core this process may use"}}
+                          "sample": f"{na} iterations of the same run in {sa:.1f} s with the waypoint index threaded PER ROLLOUT "
+                                    "(through each sample's own calls, mppi_differential_drive.py:228,:244, restarting at every "
+                                    "sample: samples independent), OpenMP over K on every core this process may use"}}
 
 
 def pmc_kernel(pmc, kernel, workgroups):
@@ -786,8 +788,8 @@ def main():
                                       ("BASELINE config 2: differential-drive analytic dynamics, K=4096 x T=50 per GPU, "
                                        "reference __main__ parameters, closed loop with the driver's plant on the device"),
                           "K_per_gpu": K_local, "K_global": K_global, "T": T,
-                          "waypoint_mode": "frozen" + (" (K-sharded)" if sharded else "") if (sharded or c4 or c5)
-                                           else "sequential (reference-exact)",
+                          "waypoint_mode": ("frozen" if (c4 or c5) else "per_rollout (K-sharded: the index threads through each sample's "
+                                            "own calls)") if (sharded or c4 or c5) else "sequential (reference-exact)",
                           "noise": "Philox4x32-10 in-kernel",
                           "timed_iterations": "closed-loop iterations %d..%d of the reference driver's run, which restarts "
                                               "from its initial state every %d iterations"

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MPPI_LIB") or os.path.join(PKG, "lib", "libmppi_hip.s
 # enums of mppi_hip.h
 MODEL_DIFFDRIVE, MODEL_RACECAR, MODEL_DIFFDRIVE_MLP = 0, 1, 2
 PREC_F32, PREC_F64 = 0, 1
-WAYPOINT_SEQUENTIAL, WAYPOINT_FROZEN = 0, 1
+WAYPOINT_SEQUENTIAL, WAYPOINT_FROZEN, WAYPOINT_PER_ROLLOUT = 0, 1, 2
 BETA_INV_EXPLORATION, BETA_INV_LAMBDA, BETA_LAMBDA = 0, 1, 2
 FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE, FILTER_TORCH = 0, 1, 2, 3
 OBSTACLE_NONE, OBSTACLE_CIRCLE, OBSTACLE_OUTLINE = 0, 1, 2

@@ -452,7 +452,11 @@ class MPPIAlgorithms(_ControllerBase):
         if self.T < 10:  # np.convolve(..., 'same') returns 10 samples and the assignment fails (:264)
             raise ValueError(f"could not broadcast input array from shape (10,) into shape ({self.T},)")
         if waypoint_mode is None:
-            waypoint_mode = "sequential" if process_group is None else "frozen"
+            # K sharded over ranks: the reference's one index cannot travel from rank to rank inside an iteration; the index
+            # still threads through every sample's own calls (:228, :244) and restarts at each sample
+            waypoint_mode = "sequential" if process_group is None else "per_rollout"
+        if waypoint_mode not in ("sequential", "frozen", "per_rollout"):
+            raise ValueError("waypoint_mode must be 'sequential', 'per_rollout' or 'frozen'")
         if learned_dynamics is not None and hasattr(learned_dynamics, "state_dict"):
             learned_dynamics = learned_dynamics.state_dict()  # a torch module (train/train_diff_mlp.py:13-36)
         cfg = dict(
@@ -463,7 +467,8 @@ class MPPIAlgorithms(_ControllerBase):
             sigma=self.Sigma, stage_cost_weight=self.stage_cost_weight, terminal_cost_weight=self.terminal_cost_weight,
             beta_mode=capi.BETA_LAMBDA if variant == "torch" else capi.BETA_INV_EXPLORATION,
             accumulate_stage_cost=0,  # `S[k] =`, :124
-            waypoint_mode=capi.WAYPOINT_SEQUENTIAL if waypoint_mode == "sequential" else capi.WAYPOINT_FROZEN,
+            waypoint_mode={"sequential": capi.WAYPOINT_SEQUENTIAL, "frozen": capi.WAYPOINT_FROZEN,
+                           "per_rollout": capi.WAYPOINT_PER_ROLLOUT}[waypoint_mode],
             search_window=10 if variant == "cuda" else 20,
             wrap_yaw_stage=0, wrap_yaw_terminal=0 if variant == "numpy" else 1,
             clamp_rollout=0 if variant == "torch" else 1,

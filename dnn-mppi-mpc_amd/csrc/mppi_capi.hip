@@ -162,6 +162,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
         FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED, "the learned-dynamics rollout runs on the f32 MFMA path only");
     if (c.precision != MPPI_PREC_F32 && c.precision != MPPI_PREC_F64)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown precision %d", c.precision);
+    if (c.waypoint_mode != MPPI_WAYPOINT_SEQUENTIAL && c.waypoint_mode != MPPI_WAYPOINT_FROZEN && c.waypoint_mode != MPPI_WAYPOINT_PER_ROLLOUT)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown waypoint_mode %d", c.waypoint_mode);
     if (c.filter_window < 1) c.filter_window = 10;
     if (c.search_window < 1)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: search_window must be >= 1");
@@ -175,14 +177,14 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if (c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && c.K_global != c.K)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
              "the sequential waypoint index threads through all samples in order and cannot be sharded; "
-             "use MPPI_WAYPOINT_FROZEN with K_global > K");
+             "use MPPI_WAYPOINT_PER_ROLLOUT or MPPI_WAYPOINT_FROZEN with K_global > K");
     if (c.n_agents < 1) c.n_agents = 1;
     if (c.n_agents > 1) {
         if (c.n_agents > 4096) FAIL((mppi_handle *)nullptr, MPPI_ERR_SHAPE, "mppi_create: n_agents %d > 4096", c.n_agents);
-        if (c.waypoint_mode != MPPI_WAYPOINT_FROZEN || c.K_global != c.K || c.model == MPPI_MODEL_DIFFDRIVE_MLP ||
-            !fused_supported(c.T) || fused_blocks(c.K, c.T, rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, c.precision == MPPI_PREC_F64)) > 512)
+        if (c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL || c.K_global != c.K || c.model == MPPI_MODEL_DIFFDRIVE_MLP ||
+            !fused_supported(c.T) || fused_blocks(c.K, c.T, rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, c.precision == MPPI_PREC_F64, c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT)) > 512)
             FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
-                 "several agents per handle need MPPI_WAYPOINT_FROZEN, an analytic model, T <= 128, at most 512 "
+                 "several agents per handle need MPPI_WAYPOINT_FROZEN or _PER_ROLLOUT, an analytic model, T <= 128, at most 512 "
                  "rollout workgroups (K <= 8192) and no sharding");
     }
     const double det = c.sigma[0] * c.sigma[3] - c.sigma[1] * c.sigma[2];
@@ -220,7 +222,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
     h->graph_on = getenv("MPPI_GRAPH") && atoi(getenv("MPPI_GRAPH")) != 0;  // (opt-in: see ensure_graph)
-    h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64);
+    h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64,
+                               c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT);
     h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K, 64);  // (mppi_set_mlp sets it again for the kernel that serves the model)
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;
@@ -566,6 +569,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     P.model = c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF;
     P.accumulate = c.accumulate_stage_cost;
     P.sequential = c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL;
+    P.per_rollout = c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT;
     P.obstacle_model = P.n_obs > 0 ? c.obstacle_model : OBS_NONE;
     P.clamp_rollout = c.clamp_rollout;
     P.wrap_stage = c.wrap_yaw_stage;

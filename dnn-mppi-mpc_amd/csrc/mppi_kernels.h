@@ -108,6 +108,9 @@ template <typename R> struct KParams {
     double x0_arg[4];
     // several agents per launch (blockIdx.y): agent a's u / S / pout / state / records / heads follow agent a-1's
     int n_agents, layout;   // layout: rollout_layout() of the handle (host side only)
+    // MPPI_WAYPOINT_PER_ROLLOUT: the index threads through a sample's own cost calls (as `sequential` threads it through
+    // all samples' calls) and starts from the x0 call's index at every sample: samples stay independent
+    int per_rollout, pad_pr;
     // one-launch resolution of the sequential index (see HYP_R): per workgroup b and entry index q
     int hyp;                // the handle qualifies (fused layout, T <= 64, window 20, `S[k] =`, one agent, <= 256 workgroups)
     R *hyp_rec;             // [blocks][HYP_R][record_len]  softmin record of workgroup b entered at c + q
@@ -192,7 +195,7 @@ const char *last_rollout_kernel();
 // Which fused rollout kernel serves (K, T): decided ONCE per handle (it reads the MPPI_DUAL / MPPI_PAIR / MPPI_SEQ
 // overrides) and carried in KParams::layout, so that a launch costs no environment lookups.
 enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
-int rollout_layout(int K, int T, int n_agents, int model, bool f64);  // n_agents: problems batched in one launch
+int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout = false);  // n_agents: problems batched in one launch
 int fused_blocks(int K, int T, int layout);  // workgroups = block records of one launch
 // records launch_rollout_fused(P) leaves (the streaming kernel, which serves tensors of noise, leaves fewer: see k_rollout_stream)
 template <typename R> int fused_records(const KParams<R> &P);

@@ -197,7 +197,11 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
         const bool act = sp.act;
         // ---- waypoint index of every call in this chunk ----------------------------------
         int my_idx;
-        if (!P.sequential) {
+        if (P.per_rollout) {  // the threading below, for every sample on its own (no first-mover bookkeeping)
+            slow = true;
+            doomed = false;
+        }
+        if (!P.sequential && !P.per_rollout) {
             const int wlen = window_len<R>(P.window, P.n_ref, c);
             if (win) {
                 const int n_act = min(64, P.T - ch * 64);
@@ -300,7 +304,7 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
             if (last_chunk) {
                 // terminal call: same state; the sequential index takes one more step (:244)
                 int idx_term = my_idx;
-                if (P.sequential && slow && !doomed) {
+                if ((P.sequential || P.per_rollout) && slow && !doomed) {
                     const R xt = wv::read_lane(x, lane_last), yt = wv::read_lane(y, lane_last);
                     p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                     idx_term = p;
@@ -2251,8 +2255,9 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
-int rollout_layout(int K, int T, int n_agents, int model, bool f64) {
-    const int kind = dual_layout(K, T, n_agents) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
+int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout) {
+    // (per-rollout index threading lives in the one-sample-per-wave kernels: Rollout::chunk)
+    const int kind = per_rollout ? LAYOUT_FUSED : dual_layout(K, T, n_agents) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
     if (kind == LAYOUT_FUSED) return kind;
     // k_rollout_dual's SEQ: two samples per (half-)wave once one sample each would need more than one workgroup per
     // CU, and at most 512 records after halving (what k_finalize merges directly).  Beyond that the longer live

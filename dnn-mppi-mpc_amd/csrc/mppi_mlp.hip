@@ -205,8 +205,9 @@ __device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLa
         }
         return from + bj;
     };
-    const int idx = nearest(P.sequential ? L.p : c);
-    if (P.sequential) L.p = idx;
+    const bool threads = P.sequential || P.per_rollout;  // the index moves with this sample's calls (:228)
+    const int idx = nearest(threads ? L.p : c);
+    if (threads) L.p = idx;
     if (P.accumulate || t == P.T - 1) {
         const bool hit = collided<false>(P, L.x, L.y, L.yaw, obs);
         float st_c = tracking_cost<float, MODEL_DIFF>(P, P.ws, P.wrap_stage, idx, L.x, L.y, L.yaw, 0.f);
@@ -216,7 +217,7 @@ __device__ __forceinline__ void mlp_advance(const KParams<float> &P, const ObsLa
         L.S = P.accumulate ? L.S + stage : stage;
         if (t == P.T - 1) {
             int idx_term = idx;
-            if (P.sequential) {  // the terminal call moves the index once more (:244)
+            if (threads) {  // the terminal call moves the index once more (:244)
                 L.p = nearest(L.p);
                 idx_term = L.p;
             }

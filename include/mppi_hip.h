@@ -53,8 +53,13 @@ typedef enum { MPPI_PREC_F32 = 0, MPPI_PREC_F64 = 1 } mppi_precision;
  *  SEQUENTIAL = one index threaded through all K*(T+1) cost calls in k-major order
  *               (mppi_differential_drive.py:228,:244, update_prev_idx=True)
  *  FROZEN     = index fixed at the nearest waypoint of x0 during rollouts
- *               (mppi_race_car.py:143,:152, default update_prev_idx=False) */
-typedef enum { MPPI_WAYPOINT_SEQUENTIAL = 0, MPPI_WAYPOINT_FROZEN = 1 } mppi_waypoint_mode;
+ *               (mppi_race_car.py:143,:152, default update_prev_idx=False)
+ *  PER_ROLLOUT = the index threads through a sample's OWN T stage calls and its terminal call exactly as the reference
+ *               threads it (:228, :244: every call searches from where the previous one ended) but starts again from the
+ *               x0 call's index at every sample -- the part of the reference's bookkeeping that survives when samples
+ *               must be independent (K sharded over GPUs, several agents per handle, all host cores in the CPU baseline);
+ *               prev_way_point_idx after the iteration = the x0 call's index, as in FROZEN */
+typedef enum { MPPI_WAYPOINT_SEQUENTIAL = 0, MPPI_WAYPOINT_FROZEN = 1, MPPI_WAYPOINT_PER_ROLLOUT = 2 } mppi_waypoint_mode;
 /* softmin rate beta in w = exp(-beta (S - rho)):
  *  INV_EXPLORATION 1/param_exploration (mppi_differential_drive.py:175)
  *  INV_LAMBDA      1/param_lambda      (mppi_race_car.py:205)

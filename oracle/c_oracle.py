@@ -70,9 +70,10 @@ class DiffDriveC:
         self.u_prev = np.zeros((self.T, 2))
         self.prev_way_point_idx = 0
 
-    def iteration(self, x0, eps, frozen_threads=0):
+    def iteration(self, x0, eps, frozen_threads=0, per_rollout_threads=0):
         """``frozen_threads`` > 0: the frozen-waypoint-index variant on that many OpenMP threads (samples independent);
-        0: the reference's sequential index, one core."""
+        ``per_rollout_threads`` > 0: the index threads through each sample's own calls and restarts at every sample
+        (samples independent too); both 0: the reference's sequential index, one core."""
         eps = np.ascontiguousarray(eps, np.float32)
         assert eps.shape == (self.K, self.T, 2)
         x0 = np.ascontiguousarray(x0, np.float64)
@@ -81,7 +82,9 @@ class DiffDriveC:
         args = (C.byref(self.cfg), _p(self.ref, C.c_double), _p(obs, C.c_double), _p(x0, C.c_double),
                 _p(eps, C.c_float), _p(self.u_prev, C.c_double), C.byref(idx), _p(S, C.c_double), _p(u0, C.c_double),
                 _p(stats, C.c_double))
-        if frozen_threads > 0:
+        if per_rollout_threads > 0:
+            rc = lib().oracle_diffdrive_iteration_independent(*args, C.c_int(int(per_rollout_threads)), C.c_int(1))
+        elif frozen_threads > 0:
             rc = lib().oracle_diffdrive_iteration_frozen(*args, C.c_int(int(frozen_threads)))
         else:
             rc = lib().oracle_diffdrive_iteration(*args)

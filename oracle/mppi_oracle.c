@@ -149,14 +149,19 @@ int oracle_diffdrive_iteration(const oracle_cfg *c, const double *ref, const dou
 }
 
 /*
- * The same iteration with the FROZEN waypoint index (every call searches the window at the x0 index, the engine's
- * MPPI_WAYPOINT_FROZEN): samples are independent then, so the K loop runs on all host cores (OpenMP).  This is the
- * all-core CPU figure of bench.py's `cpu_baseline`; the reference's own sequential index
- * (above) cannot be parallelised over samples.  Checked against the NumPy restatement in tests/test_oracle_c.py.
+ * The same iteration with a waypoint index that does not travel from sample to sample, so that samples are independent
+ * and the K loop runs on all host cores (OpenMP) -- the all-core CPU figure of bench.py's `cpu_baseline` (SURVEY.md
+ * section 8d-ii); the reference's own sequential index (above) cannot be parallelised over samples.
+ *   per_rollout = 0  FROZEN: every call searches the window at the x0 call's index (the engine's MPPI_WAYPOINT_FROZEN,
+ *                    the race-car files' semantics, mppi_race_car.py:143,152)
+ *   per_rollout = 1  PER ROLLOUT: the index threads through a sample's own T stage calls and its terminal call exactly
+ *                    as the reference threads it (:228, :244: every call searches from where the previous one ended) but
+ *                    starts again from the x0 call's index at every sample (MPPI_WAYPOINT_PER_ROLLOUT)
+ * Checked against the NumPy restatement in tests/test_oracle_c.py.
  */
-int oracle_diffdrive_iteration_frozen(const oracle_cfg *c, const double *ref, const double *obs, const double *x0,
-                                      const float *eps, double *u_prev, int *idx, double *S, double *u0_out,
-                                      double *stats, int n_threads) {
+int oracle_diffdrive_iteration_independent(const oracle_cfg *c, const double *ref, const double *obs, const double *x0,
+                                           const float *eps, double *u_prev, int *idx, double *S, double *u0_out,
+                                           double *stats, int n_threads, int per_rollout) {
     const int K = c->K, T = c->T;
     if (T < 10) return -1;
     double *u = u_prev;
@@ -183,10 +188,11 @@ int oracle_diffdrive_iteration_frozen(const oracle_cfg *c, const double *ref, co
             yaw = yaw + v1 * dt;
             x = nx;
             y = ny;
-            p = dd_nearest(ref, c->n_ref, p0, x, y); /* frozen: always from the x0 index */
+            p = dd_nearest(ref, c->n_ref, per_rollout ? p : p0, x, y); /* frozen: always from the x0 index */
             double q0 = u[2 * t] * si[0] + u[2 * t + 1] * si[2], q1 = u[2 * t] * si[1] + u[2 * t + 1] * si[3];
             s = dd_state_cost(c, c->stage_w, ref, obs, p, x, y, yaw) + gamma * (q0 * v0 + q1 * v1);
         }
+        if (per_rollout) p = dd_nearest(ref, c->n_ref, p, x, y); /* `_terminal_cost` :244 searches once more */
         S[k] = s + dd_state_cost(c, c->term_w, ref, obs, p, x, y, yaw);
     }
     *idx = p0;
@@ -217,6 +223,12 @@ int oracle_diffdrive_iteration_frozen(const oracle_cfg *c, const double *ref, co
     free(w_eps);
     free(wgt);
     return 0;
+}
+
+int oracle_diffdrive_iteration_frozen(const oracle_cfg *c, const double *ref, const double *obs, const double *x0,
+                                      const float *eps, double *u_prev, int *idx, double *S, double *u0_out,
+                                      double *stats, int n_threads) {
+    return oracle_diffdrive_iteration_independent(c, ref, obs, x0, eps, u_prev, idx, S, u0_out, stats, n_threads, 0);
 }
 
 /* ------------------------------------------------------------------------- race car -- */

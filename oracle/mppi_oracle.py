@@ -123,6 +123,29 @@ def sequential_waypoint_scan(px, py, ref_xy, p, window):
     return idx, p
 
 
+def per_rollout_waypoint_scan(X, ref_xy, p0, window):
+    """The waypoint index of every cost call when the index threads through each sample's OWN calls and starts from ``p0``
+    (the x0 call's index) at every sample -- the engine's MPPI_WAYPOINT_PER_ROLLOUT: call t of sample k does
+    ``p_k <- p_k + argmin_{j < min(window, N - p_k)} d(X[k, t], ref[p_k + j])`` (first minimum, mppi_differential_drive.py:201-220
+    with ``update_prev_idx=True``), the terminal call once more on the last state (:244).  X: [K, T, >=2].
+    Returns idx[K, T + 1] (column T: the terminal call).  Vectorised over the samples."""
+    K, T = X.shape[:2]
+    n = ref_xy.shape[0]
+    p = np.full(K, int(p0), dtype=np.int64)
+    idx = np.empty((K, T + 1), dtype=np.int64)
+    j = np.arange(window)
+    for t in range(T + 1):
+        tt = min(t, T - 1)
+        cand = p[:, None] + j[None, :]
+        ok = cand < n
+        cc = np.minimum(cand, n - 1)
+        d = (X[:, tt, 0:1] - ref_xy[cc, 0]) ** 2 + (X[:, tt, 1:2] - ref_xy[cc, 1]) ** 2
+        d = np.where(ok, d, np.inf)
+        p = p + np.argmin(d, axis=1)
+        idx[:, t] = p
+    return idx
+
+
 # --------------------------------------------------------------------------------------
 # Differential drive (f64)
 # --------------------------------------------------------------------------------------

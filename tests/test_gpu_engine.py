@@ -1093,3 +1093,96 @@ def test_streaming_rollout_of_a_noise_tensor_against_the_c_oracle(precision, T, 
         np.testing.assert_allclose(S[~finite], ref["S"][~finite], rtol=1e-6)
         assert rmse(u, ref["u_returned"]) <= 1e-4
     assert c.prev_way_point_idx == ref["idx_after"]
+
+
+@pytest.mark.parametrize("case", ["f64", "f32", "f64_obstacles", "f64_T100", "f64_two_shards"])
+def test_per_rollout_waypoint_index_against_the_c_oracle(case):
+    """MPPI_WAYPOINT_PER_ROLLOUT: the index threads through each sample's own T stage calls and its terminal call
+    (mppi_differential_drive.py:228,:244) and restarts from the x0 call's index at every sample, so samples stay
+    independent (K sharded, all host cores).  Against the plain-C restatement of that rule with injected noise: costs,
+    returned controls, the index after the iteration (= the x0 call's); the index really moves inside the rollouts here.
+    `two_shards`: the same K split over two handles (global sample index for the exploit split), merged by the split step."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    f32 = case == "f32"
+    K, T = 3000, 100 if case == "f64_T100" else 40
+    kw = dd_kwargs(K, T, param_exploration=0.05)
+    if case == "f64_obstacles":
+        kw.update(obstacle_circles=np.array([[1.0, -0.4, 0.3], [2.5, -1.4, 0.4]]), safety_margin_rate=0.8)
+    tt = np.arange(T)
+    u_in = np.stack([2.0 + 0.3 * np.sin(0.2 * tt), -0.1 + 0.05 * np.cos(0.1 * tt)], axis=1)  # fast: the rollouts run along the path
+    x0 = np.array([0.4, -0.1, -0.35])
+    eps = philox.sample_epsilon(kw["sigma"], 91, 0, K, T)
+    o = c_oracle.DiffDriveC(**kw)
+    o.u_prev[:] = u_in
+    ref = o.iteration(x0, eps, per_rollout_threads=8)
+    fz = c_oracle.DiffDriveC(**kw)
+    fz.u_prev[:] = u_in
+    assert not np.allclose(fz.iteration(x0, eps, frozen_threads=8)["S"], ref["S"], rtol=1e-3)  # the mode matters here
+    if case == "f64_two_shards":
+        from dnn_mppi_mpc_amd import _capi as capi
+        base = dict(model=capi.MODEL_DIFFDRIVE, T=T, delta_t=0.1, u_max=[5.0, 3.14], param_exploration=0.05, param_lambda=1.0,
+                    param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01], stage_cost_weight=[5, 5, 10, 0], terminal_cost_weight=[5, 5, 10, 0],
+                    search_window=20, filter_window=10, clamp_rollout=1, clamp_u_after_update=1,
+                    waypoint_mode=capi.WAYPOINT_PER_ROLLOUT, precision=capi.PREC_F64)
+        parts = [pkg.Engine(K=1700, K_global=K, k_offset=0, **base), pkg.Engine(K=1300, K_global=K, k_offset=1700, **base)]
+        eps_t = torch.from_numpy(eps).cuda()
+        recs = torch.empty((2, parts[0].partial_len()), dtype=torch.float64, device="cuda")
+        for e, (a, b) in zip(parts, ((0, 1700), (1700, 3000))):
+            e.set_ref_path(kw["ref_path"])
+            e.set_u_prev(u_in)
+        for r, (e, (a, b)) in enumerate(zip(parts, ((0, 1700), (1700, 3000)))):
+            e.step_begin(x0, eps_t[a:b].contiguous(), recs[r])
+        S = np.concatenate([e.costs() for e in parts])
+        u = parts[0].step_end(recs.reshape(-1), 2)[0]
+        np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-9)
+        assert rmse(u, ref["u_returned"]) <= 1e-8
+        return
+    c = pkg.MPPIAlgorithms(**kw, precision="f32" if f32 else "f64", waypoint_mode="per_rollout", seed=1)
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: torch.from_numpy(eps).cuda()
+    u = c._calc_input_control(x0)[1]
+    S = c.sample_costs()
+    if f32:
+        np.testing.assert_allclose(S, ref["S"], rtol=5e-4, atol=1e-3)
+        assert rmse(u, ref["u_returned"]) <= 1e-4
+    else:
+        np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-9)
+        assert rmse(u, ref["u_returned"]) <= 1e-8
+    assert c.prev_way_point_idx == ref["idx_after"] == ref["idx_start"]
+
+
+def test_per_rollout_waypoint_index_with_learned_dynamics():
+    """The same mode through the matrix-core rollout (the index is per lane = per sample there by construction): against the
+    NumPy restatement with the per-rollout scan."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    K, T = 512, 30
+    w = mppi_oracle.random_mlp_weights(3)
+    kw = dd_kwargs(K, T, param_exploration=0.05)
+    tt = np.arange(T)
+    u_in = np.stack([2.0 + 0.3 * np.sin(0.2 * tt), -0.1 + 0.05 * np.cos(0.1 * tt)], axis=1)
+    x0 = np.array([0.4, -0.1, -0.35])
+    eps = philox.sample_epsilon(kw["sigma"], 92, 0, K, T)
+    o = mppi_oracle.DiffDriveMlpOracle(**kw, mlp_weights=w)
+    v = o.clamp(np.where((np.arange(K) < mppi_oracle.exploit_threshold(kw["param_exploration"], K))[:, None, None],
+                         u_in[None] + eps, eps.astype(np.float64)))
+    X = o.rollout(x0, v)
+    p0 = o.nearest_waypoint(x0[0], x0[1], 0)
+    idx = mppi_oracle.per_rollout_waypoint_scan(X, o.ref_path[:, :2], p0, 20)
+    R, ws, wt = o.ref_path, o.stage_cost_weight, o.terminal_cost_weight
+    i_s, i_t = idx[:, T - 1], idx[:, T]
+    xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+    q = u_in[T - 1] @ np.linalg.inv(o.Sigma)
+    S_ref = (ws[0] * (xT - R[i_s, 0]) ** 2 + ws[1] * (yT - R[i_s, 1]) ** 2 + ws[2] * (yawT - R[i_s, 2]) ** 2
+             + o.param_gamma * (q[0] * v[:, -1, 0] + q[1] * v[:, -1, 1])
+             + wt[0] * (xT - R[i_t, 0]) ** 2 + wt[1] * (yT - R[i_t, 1]) ** 2 + wt[2] * (yawT - R[i_t, 2]) ** 2)
+    assert (idx[:, -1] > p0).any()
+    c = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode="per_rollout", seed=1)
+    c.u_prev[:] = u_in
+    c._calc_epsilon = lambda *a, **k: torch.from_numpy(eps).cuda()
+    c._calc_input_control(x0)
+    np.testing.assert_allclose(c.sample_costs(), S_ref, rtol=1e-3, atol=1e-3)
+    assert c.prev_way_point_idx == p0

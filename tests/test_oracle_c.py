@@ -84,3 +84,36 @@ def test_c_diffdrive_frozen_index_openmp_variant():
     wk = np.exp(-(S - S.min()) / m["param_exploration"])
     un = u + mppi_oracle.moving_average_diffdrive(np.einsum("k,ktd->td", wk / wk.sum(), eps.astype(np.float64)), 10)
     np.testing.assert_allclose(got["u_returned"], np.vstack([un[1:], un[-1:]]), rtol=1e-8, atol=1e-11)
+
+
+def test_c_diffdrive_per_rollout_openmp_variant():
+    """MPPI_WAYPOINT_PER_ROLLOUT in the C restatement (the index threads through each sample's own T + 1 cost calls,
+    mppi_differential_drive.py:228,:244, and restarts at every sample; OpenMP over the samples) against NumPy's vectorised
+    scan of the same rule."""
+    from oracle import c_oracle, mppi_oracle
+    fx = gu.load("dd_c2_k4096_moderate")
+    eps = gu.eps_of(fx)
+    m = fx["meta"]
+    o = c_oracle.DiffDriveC(**m)
+    o.u_prev[:] = fx["u_prev_in"]
+    o.prev_way_point_idx = int(fx["idx_before"])
+    got = o.iteration(fx["x0"], eps, per_rollout_threads=4)
+    n = mppi_oracle.DiffDriveOracle(**m)
+    u, x0 = fx["u_prev_in"], fx["x0"]
+    p0 = n.nearest_waypoint(x0[0], x0[1], int(fx["idx_before"]))
+    K, T = n.K, n.T
+    v = n.clamp(np.where((np.arange(K) < mppi_oracle.exploit_threshold(m["param_exploration"], K))[:, None, None],
+                         u[None] + eps, eps.astype(np.float64)))
+    X = n.rollout(x0, v)
+    idx = mppi_oracle.per_rollout_waypoint_scan(X, n.ref_path[:, :2], p0, 20)
+    assert (idx[:, -1] > p0).any()  # the index does move inside the rollouts of this fixture
+    R = n.ref_path
+    i_s, i_t = idx[:, T - 1], idx[:, T]
+    xT, yT, yawT = X[:, -1, 0], X[:, -1, 1], X[:, -1, 2]
+    ws, wt = n.stage_cost_weight, n.terminal_cost_weight
+    q = u[T - 1] @ np.linalg.inv(n.Sigma)
+    S = (ws[0] * (xT - R[i_s, 0]) ** 2 + ws[1] * (yT - R[i_s, 1]) ** 2 + ws[2] * (yawT - R[i_s, 2]) ** 2
+         + n.param_gamma * (q[0] * v[:, -1, 0] + q[1] * v[:, -1, 1])
+         + wt[0] * (xT - R[i_t, 0]) ** 2 + wt[1] * (yT - R[i_t, 1]) ** 2 + wt[2] * (yawT - R[i_t, 2]) ** 2)
+    np.testing.assert_allclose(got["S"], S, rtol=1e-10, atol=1e-10)
+    assert got["idx_after"] == p0  # the x0 call's index: the rollouts' indices do not survive the sample
