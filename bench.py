@@ -504,8 +504,13 @@ def main():
     else:
         K_global, T, episode, traverse = K_SAMPLES * world, HORIZON, EPISODE, TRAVERSE
         K_local, x_init = K_SAMPLES, X_INIT
+        # K sharded: the reference's one index cannot travel between ranks inside an iteration.  MPPI_BENCH_SHARD_MODE =
+        # frozen (default: every call searches from the x0 call's index, the race-car files' rule, 12 us per iteration) or
+        # per_rollout (the index threads through each sample's own calls, closer to :228,:244, 27 us per iteration while the
+        # robot travels: a dependent chain of T + 1 searches per sample)
+        shard_mode = os.environ.get("MPPI_BENCH_SHARD_MODE", "frozen") if sharded else None
         make = lambda: pkg.MPPIAlgorithms(**config2_kwargs(K=K_global), precision="f32", device=local_rank, seed=2024,
-                                          process_group=pg)
+                                          process_group=pg, waypoint_mode=shard_mode)
     stream = torch.cuda.current_stream()
 
     def barrier():
@@ -788,8 +793,8 @@ def main():
                                       ("BASELINE config 2: differential-drive analytic dynamics, K=4096 x T=50 per GPU, "
                                        "reference __main__ parameters, closed loop with the driver's plant on the device"),
                           "K_per_gpu": K_local, "K_global": K_global, "T": T,
-                          "waypoint_mode": ("frozen" if (c4 or c5) else "per_rollout (K-sharded: the index threads through each sample's "
-                                            "own calls)") if (sharded or c4 or c5) else "sequential (reference-exact)",
+                          "waypoint_mode": ("frozen" if (c4 or c5) else os.environ.get("MPPI_BENCH_SHARD_MODE", "frozen") + " (K-sharded)")
+                                           if (sharded or c4 or c5) else "sequential (reference-exact)",
                           "noise": "Philox4x32-10 in-kernel",
                           "timed_iterations": "closed-loop iterations %d..%d of the reference driver's run, which restarts "
                                               "from its initial state every %d iterations"

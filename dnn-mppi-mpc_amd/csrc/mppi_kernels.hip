@@ -197,8 +197,8 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
         const bool act = sp.act;
         // ---- waypoint index of every call in this chunk ----------------------------------
         int my_idx;
-        if (P.per_rollout) {  // the threading below, for every sample on its own (no first-mover bookkeeping)
-            slow = true;
+        if (P.per_rollout) {  // the threading below, for every sample on its own (no first-mover bookkeeping); a window
+            slow = window_len<R>(P.window, P.n_ref, p) > 1;  // of one candidate leaves nothing to thread
             doomed = false;
         }
         if (!P.sequential && !P.per_rollout) {
@@ -274,6 +274,16 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
         }
 
         STAMP(11);
+        costs(ch, sp, my_idx, false, 0);
+    }
+
+    // stage cost of every call of chunk `ch` (only the last one survives when !accumulate) and, in the last chunk, the
+    // terminal cost.  `my_idx`: this lane's call's waypoint index; `have_term`: the terminal call's index is `idx_term_in`
+    // (the caller threaded it), else it is taken here (one more search in the threading modes, :244)
+    __device__ __forceinline__ void costs(int ch, const Step &sp, int my_idx, bool have_term, int idx_term_in) {
+        const R *__restrict__ ref = P.ref;
+        const R x = sp.x, y = sp.y, yaw = sp.yaw, vel = sp.vel, u0 = sp.u0, u1 = sp.u1, v0 = sp.v0, v1 = sp.v1;
+        const bool act = sp.act;
         // ---- stage cost of every call (only the last one survives when !accumulate) ------
         const bool last_chunk = ch == n_chunk - 1;
         if (P.accumulate || last_chunk) {
@@ -304,7 +314,9 @@ template <typename R, int MODEL, bool OBS = true, bool PLAIN = false> struct Rol
             if (last_chunk) {
                 // terminal call: same state; the sequential index takes one more step (:244)
                 int idx_term = my_idx;
-                if ((P.sequential || P.per_rollout) && slow && !doomed) {
+                if (have_term) {
+                    idx_term = idx_term_in;
+                } else if ((P.sequential || P.per_rollout) && slow && !doomed) {
                     const R xt = wv::read_lane(x, lane_last), yt = wv::read_lane(y, lane_last);
                     p = nearest_uniform(ref, p, window_len<R>(P.window, P.n_ref, p), xt, yt, lane);
                     idx_term = p;
@@ -494,6 +506,59 @@ __device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &s
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// MPPI_WAYPOINT_PER_ROLLOUT, T <= 64: the index of every cost call when it threads through each sample's OWN calls
+// (mppi_differential_drive.py:228,:244) and restarts from the x0 call's index at every sample.  The T + 1 searches of a
+// sample are a dependent chain (call t searches from where call t-1 ended), so the lanes-over-the-horizon layout has
+// nothing to offer it: threaded by the sample's own wave (Rollout::chunk's serial loop, one wave-wide search per call)
+// it cost 33 us per iteration at config 2 against 12 us with a frozen index.  Here every wave leaves its 64 positions in
+// LDS and FOUR waves (one per SIMD) thread the indices of four samples each, a row of 16 lanes per sample over the
+// candidates of a window: per call one distance per lane (two for windows of up to 32), the row's first minimum by DPP
+// row rotations, the index advanced -- the four chains of a wave run in lockstep and the four waves side by side.
+// Out: sh_ix[sample][t] = the index call t used (t = T: the terminal call).
+// ------------------------------------------------------------------------------------------
+constexpr int PR_REF_LDS = 512;  // waypoints of the path kept in LDS for the threading (longer paths: read through the cache)
+template <typename R> __device__ __forceinline__ R row_all_min(R x) {  // min over the 16 lanes of each DPP row, in every lane
+    x = fmin(x, wv::dpp<0x128>(x, x));  // row_ror:8
+    x = fmin(x, wv::dpp<0x124>(x, x));
+    x = fmin(x, wv::dpp<0x122>(x, x));
+    x = fmin(x, wv::dpp<0x121>(x, x));
+    return x;
+}
+__device__ __forceinline__ int row_all_min(int x) {
+    x = min(x, wv::dpp<0x128>(x, x));
+    x = min(x, wv::dpp<0x124>(x, x));
+    x = min(x, wv::dpp<0x122>(x, x));
+    x = min(x, wv::dpp<0x121>(x, x));
+    return x;
+}
+template <typename R>
+__device__ __forceinline__ void per_rollout_thread(const KParams<R> &P, int c, const R (*sh_x)[64], const R (*sh_y)[64],
+                                                   const R *sh_ref /* [n][2] or null */, short (*sh_ix)[66]) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid >= 4) return;
+    const int s = 4 * wid + (lane >> 4), sub = lane & 15, T = P.T;
+    int p = c;
+    for (int t = 0; t <= T; ++t) {  // t == T: the terminal call, on the state the last stage call saw (:244)
+        const int ts = t < T ? t : T - 1;
+        const R x = sh_x[s][ts], y = sh_y[s][ts];
+        const int wl = min(P.window, P.n_ref - p);
+        R best = R(INFINITY);
+        int bj = INT_MAX;
+        for (int j = sub; j < wl; j += 16) {
+            R rx, ry;
+            if (sh_ref) { rx = sh_ref[2 * (p + j)]; ry = sh_ref[2 * (p + j) + 1]; }
+            else { rx = P.ref[4 * (p + j)]; ry = P.ref[4 * (p + j) + 1]; }
+            const R dx = x - rx, dy = y - ry;
+            const R d = dx * dx + dy * dy;
+            if (d < best) { best = d; bj = j; }
+        }
+        const R m = row_all_min(best);
+        p += row_all_min(best == m ? bj : INT_MAX);  // first minimum: the smallest offset among the nearest
+        if (sub == 0) sh_ix[s][t] = (short)p;
+    }
+}
+
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
 // SPEC: 0 general, 1 no obstacles, 2 no obstacles + the PLAIN switches (see Rollout)
@@ -539,7 +604,29 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     int mover = NO_TRIGGER;  // this wave's sample if it moved the waypoint index (sequential mode)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) { e0[ch] = 0.f; e1[ch] = 0.f; }
-    if (valid) {
+    // MPPI_WAYPOINT_PER_ROLLOUT on horizons of one chunk: positions -> LDS, four waves thread the indices, costs (see
+    // per_rollout_thread); a window of one candidate leaves nothing to thread
+    const bool pr_fast = !PLAIN && NCH == 1 && P.per_rollout && wlen0 > 1 && P.n_ref < 32768;
+    if (pr_fast) {
+        __shared__ R sh_px[FUSED_WAVES][64], sh_py[FUSED_WAVES][64];
+        __shared__ short sh_ix[FUSED_WAVES][66];
+        __shared__ R sh_pref[2 * PR_REF_LDS];
+        const bool ref_lds = P.n_ref <= PR_REF_LDS;
+        if (ref_lds)
+            for (int i = threadIdx.x; i < P.n_ref; i += blockDim.x) { sh_pref[2 * i] = P.ref[4 * i]; sh_pref[2 * i + 1] = P.ref[4 * i + 1]; }
+        Rollout<R, MODEL, OBS, PLAIN> r(P, sv, k, lane, nullptr, obs, agent);
+        typename Rollout<R, MODEL, OBS, PLAIN>::Step sp{R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0), false};
+        if (valid) sp = r.dynamics(0, e0[0], e1[0]);
+        sh_px[wid][lane] = sp.x;
+        sh_py[wid][lane] = sp.y;
+        __syncthreads();
+        per_rollout_thread<R>(P, sv.c, sh_px, sh_py, ref_lds ? sh_pref : nullptr, sh_ix);
+        __syncthreads();
+        if (valid) {
+            r.costs(0, sp, (int)sh_ix[wid][lane < P.T ? lane : 0], true, (int)sh_ix[wid][P.T]);
+            S_k = r.finish(false);
+        }
+    } else if (valid) {
         Rollout<R, MODEL, OBS, PLAIN> r(P, sv, k, lane, use_win ? sh_win : nullptr, obs, agent);
         r.sh_first = seq_search ? &sh_first : nullptr;
         if (k >= k_start) {
@@ -2340,7 +2427,8 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
 #undef MPPI_LAUNCH_DUAL
     default:
         {
-            const bool plain = P.obstacle_model == OBS_NONE && P.use_philox && P.clamp_rollout && !P.wrap_stage && !P.wrap_term;
+            const bool plain = P.obstacle_model == OBS_NONE && P.use_philox && P.clamp_rollout && !P.wrap_stage && !P.wrap_term &&
+                               !P.per_rollout;
             const int spec = plain ? 2 : P.obstacle_model == OBS_NONE ? 1 : 0;
             const dim3 block(64 * FUSED_WAVES);
 #define MPPI_LAUNCH_FUSED(NCH_, SPEC_)                                                                                  \
