@@ -162,6 +162,42 @@ def batched_agents(n_agents=32, iters=400):
                     "over the WHOLE iteration (serial tail included), so a lower bound on the rollout launch's own fraction"}
 
 
+def strong_scaling_bound_c4(t_full, ranks=8):
+    """What K sharded over `ranks` GPUs can gain at config 4 BEFORE any exchange: one shard's iteration (K / ranks samples, the
+    same closed loop, measured here on this GPU) against the whole K's.  The serial tail of an iteration (merge, filter,
+    plant, next x0 call, two kernel boundaries) does not shrink with the shard, so the ratio stays below `ranks`."""
+    import torch
+    import dnn_mppi_mpc_amd as pkg
+    K, T = 65536 // ranks, 75
+    x_init = config4_path()[0].astype(np.float64)
+    ctrl = pkg.MPPIRacecarController(**config4_kwargs(K, T), precision="f32", device=torch.cuda.current_device(), seed=2024)
+    eng = ctrl._engine
+
+    def run(n):
+        done = 0
+        while done < n:  # the driver's loop runs over its 100 waypoints (mppi_race_car_obstacle.py:336)
+            if done % 100 == 0:
+                ctrl.restart_episode(x_init)
+            m = min(n - done, 100 - done % 100)
+            eng.run_closed_loop(m)
+            done += m
+    run(100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(600)
+    torch.cuda.synchronize()
+    t_shard = (time.perf_counter() - t0) / 600
+    eng.enable_timing(True)
+    run(200)
+    kms = eng.last_kernel_ms()
+    eng.enable_timing(False)
+    return {"ranks": ranks, "K_per_rank": K, "us_per_iteration_whole_K_one_gpu": 1e6 * t_full, "us_per_iteration_one_shard": 1e6 * t_shard,
+            "speedup_bound_before_exchange": t_full / t_shard,
+            "shard_kernel_us": {"rollout": 1e3 * kms["rollout"], "merge": 1e3 * kms["reduce"], "finalize": 1e3 * kms["finalize"]},
+            "note": "measured on this one GPU (a shard's rollout does not depend on the others'); the exchange of the per-rank "
+                    "records (824 B per rank, inside k_finalize or one collective) comes on top"}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -810,6 +846,8 @@ def main():
                                     "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "roofline": roof}
+        if world == 1 and c4:
+            out["strong_scaling_bound"] = strong_scaling_bound_c4(1e-3 * out["ms_per_step"])
         if world == 1 and not c3 and not c4 and not c5 and not args.no_batched:
             out["batched_agents"] = batched_agents()
         if world == 1 and not c3 and not c4 and not c5 and not args.no_cpu_baseline:  # (the C restatement timed is config 2's)

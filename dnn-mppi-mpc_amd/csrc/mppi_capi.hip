@@ -650,6 +650,7 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.n_ref = h->n_ref;
     F.window = c.search_window;
     F.is_f64 = h->f64;
+    F.count_hits = c.obstacle_model != MPPI_OBSTACLE_NONE && h->n_obs > 0;
     F.beta = c.beta_mode == MPPI_BETA_INV_EXPLORATION ? 1.0 / c.param_exploration
              : c.beta_mode == MPPI_BETA_INV_LAMBDA    ? 1.0 / c.param_lambda
                                                       : c.param_lambda;

@@ -123,7 +123,7 @@ struct FinalizeParams {
     int T, K, n_part, pad2;
     int filter_mode, filter_window, clamp_u, raise_at_path_end;
     int model, sequential, plant, n_ref;
-    int window, is_f64, pad0, pad1;
+    int window, is_f64, count_hits, pad1;  // count_hits: the block records' heads carry collision counts (a handle with obstacles)
     double beta, dt, wheel_base, umax0, umax1;
     const void *partials;    // [n_part][partial_len], n_part <= 256; element type: see launch_finalize
     const void *heads;       // compact heads of `partials` (KParams::heads); unused for the ABI layout

@@ -651,7 +651,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     // rho_b = min over the workgroup's 16 costs: lane w of a row reads sample w's, four DPP steps fold the row (every wave
     // needs it: 16 reads + 15 minima per wave took a twelfth of the launch's VALU instructions)
     static_assert(FUSED_WAVES == 16, "one DPP row of costs");
-    const R rho = wv::read_lane(wv::scan_incl_row<wv::OpMin>(sh_S[lane & 15]), 15);
+    const R sv_l = sh_S[lane & 15];
+    const R rho = wv::read_lane(wv::scan_incl_row<wv::OpMin>(sv_l), 15);
+    // (samples whose cost carries a collision penalty, mppi_stats::n_collided: one ballot over the costs read above)
+    const int n_hit_i = OBS ? __popcll(__ballot(sv_l >= P.penalty && sv_l < R(INFINITY)) & 0xffffull) : 0;
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
     if (lane == 0) sh_e[wid] = e;
 #pragma unroll
@@ -670,13 +673,13 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     }
     if (threadIdx.x == 64 * (FUSED_WAVES - 1)) {  // a lane of the last wave: the first ones carry the column sums
         // (the head's fourth word: how many of the workgroup's samples carry a collision penalty in their cost -- mppi_stats::n_collided)
-        R eta = 0, eta2 = 0, n_hit = 0;
+        R eta = 0, eta2 = 0;
+        const R n_hit = (R)n_hit_i;
 #pragma unroll
         for (int w = 0; w < FUSED_WAVES; ++w) {
             const R ew = sh_e[w];
             eta += ew;
             eta2 += ew * ew;
-            if (OBS) n_hit += (sh_S[w] >= P.penalty && sh_S[w] < R(INFINITY)) ? R(1) : R(0);
         }
         out[0] = rho;
         out[1] = eta;
@@ -1004,8 +1007,15 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
     }
     STAMP(3);
     R s_min = R(INFINITY);
+    int n_hit_i = 0;  // samples of the workgroup whose cost carries a collision penalty (mppi_stats::n_collided): a ballot per
+                      // pass over the costs every lane reads here anyway (a loop by the record's thread cost config 3 1.3 us)
 #pragma unroll
-    for (int i = 0; i < SAMPLES; i += HL) s_min = fmin(s_min, i + l32 < SAMPLES ? sh_S[i + l32] : R(INFINITY));
+    for (int i = 0; i < SAMPLES; i += HL) {
+        const R sv_i = i + l32 < SAMPLES ? sh_S[i + l32] : R(INFINITY);
+        s_min = fmin(s_min, sv_i);
+        const unsigned long long hb = __ballot(sv_i >= P.penalty && sv_i < R(INFINITY));
+        n_hit_i += __popcll(HL == 64 ? hb : (hb & 0xffffffffull));
+    }
     const R rho = wv::read_lane(wv::scan_incl_seg<wv::OpMin, SPW>(s_min), HL - 1);
     const R e = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // :175
     const R e_first = SEQ == 2 && valid_first ? mf::exp_(-P.beta * (S_first - rho)) : R(0);
@@ -1032,14 +1042,13 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
         out[4 + i] = acc;
     }
     if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
-        R eta = 0, eta2 = 0, n_hit = 0;
-        const bool count_hits = P.obstacle_model != OBS_NONE;
+        R eta = 0, eta2 = 0;
+        const R n_hit = P.obstacle_model != OBS_NONE ? (R)n_hit_i : R(0);
 #pragma unroll
         for (int q = 0; q < SAMPLES; ++q) {
             const R ew = sh_e[q];
             eta += ew;
             eta2 += ew * ew;
-            if (count_hits) n_hit += (sh_S[q] >= P.penalty && sh_S[q] < R(INFINITY)) ? R(1) : R(0);
         }
         out[0] = rho;
         out[1] = eta;
@@ -1537,7 +1546,7 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
     }
     eta = wv::reduce<wv::OpAdd>(eta);
     eta2 = wv::reduce<wv::OpAdd>(eta2);
-    if (n_hit) {
+    if (n_hit && *n_hit >= A(0)) {  // (the caller asks for the count by passing 0, and leaves it out with -1: no obstacles)
         A cnt = 0;
 #pragma unroll
         for (int i = 0; i < 4 * NWIN; ++i) cnt += lane + 64 * i < n ? m.hc[i] : A(0);
@@ -1925,12 +1934,15 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     auto store_w = [&](int i, A v) { filter_store<A>(sh_w, i, v, T, H, pad_copy); };
     A rho, eta, eta2;
     A n_hit = A(-1);  // (-1: not known -- the records of other ranks carry no count)
+    const bool count_hits = F.count_hits != 0;  // (a handle with obstacles: the block records carry the count)
     if (ABI_RECS) {
         merge_abi<A>(reinterpret_cast<const double *>(F.partials), F.n_part, T, (A)F.beta, L.s, L.red, rho, eta, eta2,
                      store_w);
     } else if (!XCHG) {
+        if (count_hits) n_hit = A(0);
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
                                    eta, eta2, store_w, sel, &n_hit);
+        if (!count_hits) n_hit = A(0);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
