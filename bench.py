@@ -421,10 +421,15 @@ def launch_ranks(n, argv):
     chunks, rc = [], 0
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    deadline = time.time() + float(os.environ.get("MPPI_BENCH_RANK_TIMEOUT_S", "1500"))
     try:
         while any(p.poll() is None for p in procs):
             if any(p.poll() not in (None, 0) for p in procs):
                 break  # a rank failed: the others would wait for it at the next barrier or exchange
+            if time.time() > deadline:
+                print("bench.py: the ranks did not finish within MPPI_BENCH_RANK_TIMEOUT_S; stopping them", file=sys.stderr)
+                rc = 1
+                break
             time.sleep(0.05)
     finally:
         for p in procs:  # a rank that failed (or an interrupt here) must not leave the others waiting at a barrier
