@@ -1080,10 +1080,6 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
 // The frozen index makes every cost call of a sample search the SAME window [c, c + wlen) and `S[k] =` keeps only the
 // last step's: one search per sample, its <= 32 candidates spread over the lanes of the half-wave.
 // ------------------------------------------------------------------------------------------
-// workgroup barrier that orders LDS traffic only: `__syncthreads()` also waits for every outstanding vector-memory access
-// (s_waitcnt vmcnt(0))
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // PHILOX: the same loop with the noise drawn in registers (one Philox4x32 block per lane feeds its two steps, as in
 // k_rollout_dual) -- the frozen-index `S[k] =` form then also pays one search per sample instead of one per lane and step,
 // no workgroup barrier per 32 samples and one record per workgroup: 32 batched config-2 agents 63 -> ~35 us per launch.
