@@ -164,6 +164,10 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown precision %d", c.precision);
     if (c.waypoint_mode != MPPI_WAYPOINT_SEQUENTIAL && c.waypoint_mode != MPPI_WAYPOINT_FROZEN && c.waypoint_mode != MPPI_WAYPOINT_PER_ROLLOUT)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: unknown waypoint_mode %d", c.waypoint_mode);
+    if (c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT && c.model == MPPI_MODEL_RACECAR)
+        FAIL((mppi_handle *)nullptr, MPPI_ERR_UNSUPPORTED,
+             "MPPI_WAYPOINT_PER_ROLLOUT restates the diff-drive files' index bookkeeping (mppi_differential_drive.py:228,:244); "
+             "the race-car files search from the x0 call's index (MPPI_WAYPOINT_FROZEN)");
     if (c.filter_window < 1) c.filter_window = 10;
     if (c.search_window < 1)
         FAIL((mppi_handle *)nullptr, MPPI_ERR_BAD_ARG, "mppi_create: search_window must be >= 1");
@@ -804,8 +808,12 @@ static int check_ready(mppi_handle *h, const char *who) {
         if ((h)->B > 1) FAIL(h, MPPI_ERR_UNSUPPORTED, "%s serves single-agent handles (n_agents = %d)", who, (h)->B); \
     } while (0)
 
-static void fill_stats(const mppi_handle *h, mppi_stats *stats) {
+static void fill_stats(mppi_handle *h, mppi_stats *stats) {
     if (!stats) return;
+    if (h->timing && h->ev_used >= EV_PER_SLOT) {  // kernel_us: the window's averages as of this call
+        if (hipEventSynchronize(h->ev[h->ev_used - 1]) == hipSuccess) collect_timing(h);
+        else (void)hipGetLastError();
+    }
     const StepResult *r = h->h_res;
     stats->rho = r->rho;
     stats->eta = r->eta;

@@ -58,7 +58,8 @@ typedef enum { MPPI_PREC_F32 = 0, MPPI_PREC_F64 = 1 } mppi_precision;
  *               threads it (:228, :244: every call searches from where the previous one ended) but starts again from the
  *               x0 call's index at every sample -- the part of the reference's bookkeeping that survives when samples
  *               must be independent (K sharded over GPUs, several agents per handle, all host cores in the CPU baseline);
- *               prev_way_point_idx after the iteration = the x0 call's index, as in FROZEN */
+ *               prev_way_point_idx after the iteration = the x0 call's index, as in FROZEN.  Diff-drive models only (the
+ *               race-car files have no such bookkeeping: MPPI_ERR_UNSUPPORTED) */
 typedef enum { MPPI_WAYPOINT_SEQUENTIAL = 0, MPPI_WAYPOINT_FROZEN = 1, MPPI_WAYPOINT_PER_ROLLOUT = 2 } mppi_waypoint_mode;
 /* softmin rate beta in w = exp(-beta (S - rho)):
  *  INV_EXPLORATION 1/param_exploration (mppi_differential_drive.py:175)
@@ -148,8 +149,7 @@ typedef struct {
     double iter_us;       /* host wall time per iteration of the call that filled this struct (mppi_step: the call;
                              mppi_run_closed_loop: the call divided by its iterations), microseconds */
     double kernel_us;     /* rollout + merge + finalize kernel time per iteration by HIP events on the launch stream: the
-                             average over the last window of mppi_enable_timing, as of the last mppi_last_kernel_ms call;
-                             0 while timing is off */
+                             average over the window since mppi_enable_timing(h, 1), as of this call; 0 while timing is off */
 } mppi_stats;
 
 typedef struct mppi_handle mppi_handle;

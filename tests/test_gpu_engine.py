@@ -143,6 +143,12 @@ def test_stats_collision_count_across_layouts():
     c = pkg.MPPIAlgorithms(**dd_kwargs(700, 30), precision="f32", seed=3)
     c._calc_input_control(x0)
     assert c.last_stats.n_collided == 0
+    assert c.last_stats.kernel_us == 0.0 and c.last_stats.iter_us > 0.0  # (kernel time only while timing is enabled)
+    c._engine.enable_timing(True)
+    c._engine.set_state(x0)
+    _, st = c._engine.run_closed_loop(50)
+    assert 0.5 < st.kernel_us < st.iter_us * 1.5, (st.kernel_us, st.iter_us)  # rollout + finalize by events: microseconds
+    c._engine.enable_timing(False)
     lem = mppi_oracle.generate_lemniscate_racecar(100, 10.0)
     rc = pkg.MPPIRacecarController(ref_path=lem, horizon_step_T=75, number_of_samples_K=3000, obstacle_circles=np.array([[5.0, 5.0, 1.0], [7.0, 7.0, 1.0]]),
                                    visualize_optimal_traj=False, visualze_sampled_trajs=False, precision="f32", seed=5)
@@ -1186,3 +1192,55 @@ def test_per_rollout_waypoint_index_with_learned_dynamics():
     c._calc_input_control(x0)
     np.testing.assert_allclose(c.sample_costs(), S_ref, rtol=1e-3, atol=1e-3)
     assert c.prev_way_point_idx == p0
+
+
+def test_per_rollout_batched_agents_and_unsupported_combinations():
+    """MPPI_WAYPOINT_PER_ROLLOUT with several agents per handle (agents as a grid dimension of the same kernels) against
+    the agents run one by one; the race-car model has no such bookkeeping and is refused."""
+    import dnn_mppi_mpc_amd as pkg
+    from dnn_mppi_mpc_amd import _capi as capi
+    B, K, T, n_it = 3, 400, 40, 5
+    ref = mppi_oracle.generate_point_trajectory((0.0, 0.0), (10.0, -5.0), 100)
+    base = dict(model=capi.MODEL_DIFFDRIVE, T=T, delta_t=0.1, u_max=[5.0, 3.14], param_exploration=0.05, param_lambda=1.0,
+                param_alpha=0.2, sigma=[0.1, 0.0, 0.0, 0.01], stage_cost_weight=[5, 5, 10, 0], terminal_cost_weight=[5, 5, 10, 0],
+                search_window=20, filter_window=10, clamp_rollout=1, waypoint_mode=capi.WAYPOINT_PER_ROLLOUT, seed=13,
+                precision=capi.PREC_F64)
+    x0 = np.stack([[0.2 * a, -0.1 * a, 0.1 * a - 0.4] for a in range(B)])
+    tt = np.arange(T)
+    u_in = np.stack([np.stack([2.0 + 0.2 * a + 0.3 * np.sin(0.2 * tt), -0.1 + 0.05 * np.cos(0.1 * tt)], axis=1) for a in range(B)])
+    batch = pkg.Engine(K=K, n_agents=B, **base)
+    batch.set_ref_path(ref)
+    batch.set_state(x0)
+    batch.set_u_prev(u_in)
+    batch.run_closed_loop(n_it)
+    for a in range(B):
+        one = pkg.Engine(K=K, noise_stream=a, **base)
+        one.set_ref_path(ref)
+        one.set_state(x0[a])
+        one.set_u_prev(u_in[a])
+        one.run_closed_loop(n_it)
+        np.testing.assert_allclose(batch.get_u_prev()[a], one.get_u_prev(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(batch.costs()[a], one.costs(), rtol=1e-12, atol=1e-14)
+    with pytest.raises(pkg.MppiError) as ex:
+        pkg.Engine(K=K, **dict(base, model=capi.MODEL_RACECAR, wheel_base=2.5))
+    assert ex.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_noise_ring_with_learned_dynamics():
+    """The noise ring through the matrix-core rollout: a closed loop reading the sampler's own tensors from the ring equals
+    the closed loop that draws them in the kernel."""
+    import torch
+
+    import dnn_mppi_mpc_amd as pkg
+    w = mppi_oracle.random_mlp_weights(5)
+    kw = dd_kwargs(256, 20, param_exploration=0.05)
+    a = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode="frozen", seed=8)
+    b = pkg.MPPIAlgorithms(**kw, learned_dynamics=w, waypoint_mode="frozen", seed=8)
+    for c in (a, b):
+        c._engine.set_state(np.array([0.1, -0.05, 0.2]))
+    ring = torch.stack([b._engine.sample_epsilon(i) for i in range(4)])
+    b._engine.set_noise_ring(ring)
+    a._engine.run_closed_loop(4)
+    b._engine.run_closed_loop(4)
+    np.testing.assert_allclose(b._engine.get_u_prev(), a._engine.get_u_prev(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(b._engine.get_state(), a._engine.get_state(), rtol=0, atol=1e-6)
