@@ -40,10 +40,9 @@ struct mppi_handle {
     void *d_heads = nullptr, *d_heads2 = nullptr;  // compact {rho, eta, eta2, 0} of d_partials / d_partials2
     float *d_mlp = nullptr;         // packed residual-model weights (config 5)
     unsigned short *d_mlp16 = nullptr;  // the same as f16 hi / lo planes (k_rollout_mlp_h3)
-    // one-launch resolution of the sequential waypoint index (HYP_R in mppi_kernels.h)
+    // one-launch resolution of the sequential waypoint index (LB_CAND in mppi_kernels.h)
     bool hyp = false;
-    void *d_hyp_rec = nullptr, *d_hyp_heads = nullptr, *d_hyp_S = nullptr;
-    unsigned char *d_hyp_map = nullptr, *d_hyp_q = nullptr;
+    unsigned *d_hyp_slots = nullptr;  // one look-back word per workgroup
     std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
     StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
     long long seq = 0;
@@ -266,17 +265,8 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
              c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && (c.search_window == HYP_WINDOW || c.search_window == HYP_WINDOW_CUDA) &&
              c.n_agents == 1 && h->n_part <= HYP_MAX_BLOCKS && !getenv("MPPI_NO_HYP");
     if (h->hyp) {
-        const size_t nrec = (size_t)HYP_MAX_BLOCKS * HYP_R;
-        if ((e = hipMalloc(&h->d_hyp_rec, rec_bytes * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp records)");
-        if ((e = hipMalloc(&h->d_hyp_heads, 32 * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp heads)");
-        if ((e = hipMalloc(&h->d_hyp_S, sizeof(double) * 16 * nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp costs)");
-        if ((e = hipMalloc((void **)&h->d_hyp_map, nrec)) != hipSuccess) return fail(e, "hipMalloc(hyp maps)");
-        if ((e = hipMalloc((void **)&h->d_hyp_q, HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMalloc(hyp entries)");
-        if ((e = hipMemset(h->d_hyp_rec, 0, rec_bytes * nrec)) != hipSuccess) return fail(e, "hipMemset");
-        if ((e = hipMemset(h->d_hyp_heads, 0, 32 * nrec)) != hipSuccess) return fail(e, "hipMemset");
-        if ((e = hipMemset(h->d_hyp_S, 0, sizeof(double) * 16 * nrec)) != hipSuccess) return fail(e, "hipMemset");
-        if ((e = hipMemset(h->d_hyp_map, 0, nrec)) != hipSuccess) return fail(e, "hipMemset");
-        if ((e = hipMemset(h->d_hyp_q, 0, HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipMalloc((void **)&h->d_hyp_slots, sizeof(unsigned) * HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMalloc(look-back words)");
+        if ((e = hipMemset(h->d_hyp_slots, 0, sizeof(unsigned) * HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMemset");
     }
     h->res_bytes = (h->res_bytes + 15) & ~(size_t)15;  // (the agents' results are stored back to back)
     if ((e = hipMalloc((void **)&h->d_st, B * sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");
@@ -311,8 +301,7 @@ extern "C" int mppi_destroy(mppi_handle *h) {
     hipSetDevice(h->cfg.device);
     if (h->xbuf || h->rccl_comm) mppi_comm_close(h);
     void *bufs[] = {h->d_ref, h->d_obs, h->d_u, h->d_uhist, h->d_S, h->d_pout, h->d_partials, h->d_partials2, h->d_mlp,
-                    h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2, h->d_hyp_rec, h->d_hyp_heads,
-                    h->d_hyp_S, h->d_hyp_map, h->d_hyp_q, h->d_mlp16};
+                    h->d_w,   h->d_trace, h->d_st, h->d_res, h->d_heads, h->d_heads2, h->d_hyp_slots, h->d_mlp16};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_res) hipHostFree(h->h_res);
@@ -630,10 +619,8 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     // the kernels that can resolve the sequential index in one launch -- while that index can still move: once it sits
     // on the last waypoint (it only grows) every search window holds one candidate and the lean kernels serve
     P.hyp = h->hyp && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
-    P.hyp_rec = (R *)h->d_hyp_rec;
-    P.hyp_heads = (R *)h->d_hyp_heads;
-    P.hyp_map = h->d_hyp_map;
-    P.hyp_S = (R *)h->d_hyp_S;
+    P.pad_hyp = 0;
+    P.hyp_slots = h->d_hyp_slots;
     return P;
 }
 
@@ -679,12 +666,7 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.u0_trace = nullptr;
     F.hyp = h->hyp && partials == h->d_partials && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
     F.hyp_blocks = h->n_part;
-    F.hyp_rec = h->d_hyp_rec;
-    F.hyp_heads = h->d_hyp_heads;
-    F.hyp_S = h->d_hyp_S;
-    F.hyp_map = h->d_hyp_map;
-    F.hyp_q = h->d_hyp_q;
-    F.S = h->d_S;
+    F.hyp_slots = h->d_hyp_slots;
     return F;
 }
 
@@ -1067,23 +1049,10 @@ extern "C" int mppi_sync_result(mppi_handle *h, double *u_out, double *u0_out, m
     return MPPI_OK;
 }
 
-// S[K] on the device: an iteration that ended in the one-launch resolution of the waypoint index leaves the costs per
-// workgroup and entry index (StepResult::costs_hyp); pick the realised ones
-static int materialise_costs(mppi_handle *h) {
-    if (!h->hyp || !h->h_res->costs_hyp) return MPPI_OK;
-    if (h->f64) launch_gather_costs<double>((const double *)h->d_hyp_S, h->d_hyp_q, (double *)h->d_S, h->cfg.K, nullptr);
-    else launch_gather_costs<float>((const float *)h->d_hyp_S, h->d_hyp_q, (float *)h->d_S, h->cfg.K, nullptr);
-    HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipDeviceSynchronize());
-    h->h_res->costs_hyp = 0;
-    return MPPI_OK;
-}
-
 extern "C" int mppi_get_costs(mppi_handle *h, double *S) {
     if (!h || !S) return MPPI_ERR_BAD_ARG;
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    if (int rc = materialise_costs(h)) return rc;
     return download_real(h, S, h->d_S, (size_t)h->B * h->cfg.K);  // [n_agents][K]
 }
 
@@ -1092,7 +1061,6 @@ extern "C" int mppi_get_weights(mppi_handle *h, double *w) {
     SINGLE_AGENT_ONLY(h, "mppi_get_weights");
     HIPCHECK(h, hipSetDevice(h->cfg.device));
     HIPCHECK(h, hipDeviceSynchronize());
-    if (int rc = materialise_costs(h)) return rc;
     if (!h->d_w) HIPCHECK(h, hipMalloc((void **)&h->d_w, sizeof(double) * h->cfg.K));
     if (h->f64) {
         KParams<double> P = make_params<double>(h, nullptr);

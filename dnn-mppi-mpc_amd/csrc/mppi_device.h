@@ -129,81 +129,6 @@ template <typename R> __device__ __forceinline__ int window_len(int window, int 
     return rem < window ? rem : window;
 }
 
-// ---- one-launch resolution of the sequential index (HYP_R in mppi_kernels.h) -------------------------------------
-// The candidates ref[c .. c + HYP_R + W - 2] as pairs (see RefPair), W = the search window (20: the NumPy / torch files,
-// 10: `_cuda`, mppi_differential_drive_cuda.py:201); candidates past the end of the path are far-away points that can
-// never win, so every window [q, q+W) is truncated at the path's end like the reference's slice
-// (mppi_differential_drive.py:206-208).
-template <typename R>
-__device__ __forceinline__ void hyp_stage_window(RefPair<R> *sh, const R *__restrict__ ref, int c, int n_ref, int tid,
-                                                 int window = HYP_WINDOW) {
-    const int cand = HYP_R + window - 1;
-    if (tid < (cand + 1) / 2) {
-        const int j0 = c + 2 * tid, j1 = j0 + 1;
-        const bool h0 = j0 < n_ref, h1 = j1 < n_ref && 2 * tid + 1 < cand;
-        RefPair<R> r;
-        r.x0 = h0 ? ref[4 * j0] : R(1e30);
-        r.y0 = h0 ? ref[4 * j0 + 1] : R(1e30);
-        r.x1 = h1 ? ref[4 * j1] : R(1e30);
-        r.y1 = h1 ? ref[4 * j1 + 1] : R(1e30);
-        sh[tid] = r;
-    }
-}
-
-// This lane's call as a table: g(q) = offset of the first nearest candidate in [q, q+W), q = 0 .. HYP_R-1 (one byte
-// each), for the position (x, y).  Sliding-window first minimum in one pass over the HYP_R + W - 1 candidates, cut into
-// blocks of W: a window [q, q+W) is a suffix of its block followed by a prefix of the next one.  Running first minimum
-// from the LEFT inside every block but the first (a window's part beyond its block's end), from the RIGHT inside the
-// blocks that hold an entry offset (its part up to the block's end; `<=` hands ties to the smaller index), and per q the
-// smaller of the two with ties to the left part.  W = 20: blocks [0, 20) and [20, 35); W = 10: [0, 10), [10, 20), [20, 25).
-struct alignas(16) HypTable { unsigned w[HYP_R / 4]; };
-template <int W, typename R> __device__ __forceinline__ HypTable hyp_table_w(const RefPair<R> *win, R x, R y) {
-    static_assert(HYP_R == 16 && W >= 2 && W <= HYP_WINDOW, "hyp_table: 16 entries, a window of at most HYP_WINDOW candidates");
-    constexpr int CAND = HYP_R + W - 1;
-    auto dist = [&](int i) {
-        const RefPair<R> r = win[i >> 1];
-        const R dx = x - ((i & 1) ? r.x1 : r.x0), dy = y - ((i & 1) ? r.y1 : r.y0);
-        return dx * dx + dy * dy;
-    };
-    // prefix first minima of candidates W .. CAND-1, restarting at every block start
-    R pv[CAND - W];
-    int pi[CAND - W];
-    {
-        R best = R(INFINITY);
-        int bi = W;
-#pragma unroll
-        for (int i = W; i < CAND; ++i) {
-            const R d = dist(i);
-            if (i % W == 0 || d < best) { best = d; bi = i; }
-            pv[i - W] = best;
-            pi[i - W] = bi;
-        }
-    }
-    HypTable g;
-#pragma unroll
-    for (int q = 0; q < HYP_R / 4; ++q) g.w[q] = 0u;
-    // suffix first minima from the end of the last block that holds an entry offset, restarting at every block end
-    constexpr int TOP = ((HYP_R - 1) / W + 1) * W - 1;  // last candidate of the block of entry HYP_R - 1 (all < CAND)
-    static_assert(TOP < CAND, "the block of the last entry offset lies inside the candidates");
-    R sv = R(INFINITY);
-    int si = TOP;
-#pragma unroll
-    for (int i = TOP; i >= 0; --i) {
-        const R d = dist(i);
-        if (i % W == W - 1 || d <= sv) { sv = d; si = i; }
-        if (i < HYP_R) {
-            int gi = si;
-            // the window [i, i+W-1] reaches into the next block unless i starts a block (then it IS the block)
-            if (i % W != 0 && pv[i - 1] < sv) gi = pi[i - 1];  // prefix of the next block up to candidate i + W - 1
-            g.w[i >> 2] |= (unsigned)gi << (8 * (i & 3));
-        }
-    }
-    return g;
-}
-template <typename R> __device__ __forceinline__ HypTable hyp_table(const RefPair<R> *win, R x, R y, int window = HYP_WINDOW) {
-    return window == HYP_WINDOW_CUDA ? hyp_table_w<HYP_WINDOW_CUDA, R>(win, x, y) : hyp_table_w<HYP_WINDOW, R>(win, x, y);
-}
-
 // collision indicator of one state (mppi_differential_drive_obs.py:301-313,
 // mppi_race_car_obstacle.py:241-274)
 // The obstacle table lives in registers: lane m holds circle m {centre, squared radius} (one vector load issued at
@@ -281,9 +206,8 @@ __device__ __forceinline__ bool collided(const KParams<R> &P, R x, R y, R yaw, c
 
 // weighted squared tracking error against waypoint i (`_compute_cost` :222-236, `_c` mppi_race_car.py:137-146)
 template <typename R, int MODEL>
-__device__ __forceinline__ R tracking_cost(const KParams<R> &P, const R (&w)[4], bool wrap, int i, R x, R y, R yaw,
-                                           R vel) {
-    const R *r = P.ref + 4 * i;
+__device__ __forceinline__ R tracking_cost_row(const KParams<R> &P, const R (&w)[4], bool wrap, const R *r, R x, R y, R yaw,
+                                               R vel) {  // r: the waypoint's row {x, y, yaw, v}
     if (wrap) yaw = mf::pymod(yaw + P.two_pi, P.two_pi);
     const R ex = x - r[0], ey = y - r[1], eyaw = yaw - r[2];
     R c = w[0] * (ex * ex) + w[1] * (ey * ey) + w[2] * (eyaw * eyaw);
@@ -292,6 +216,11 @@ __device__ __forceinline__ R tracking_cost(const KParams<R> &P, const R (&w)[4],
         c += w[3] * (ev * ev);
     }
     return c;
+}
+template <typename R, int MODEL>
+__device__ __forceinline__ R tracking_cost(const KParams<R> &P, const R (&w)[4], bool wrap, int i, R x, R y, R yaw,
+                                           R vel) {
+    return tracking_cost_row<R, MODEL>(P, w, wrap, P.ref + 4 * i, x, y, yaw, vel);
 }
 
 

@@ -22,15 +22,24 @@ __host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
 }
 
 // Sequential waypoint index resolved in ONE launch (mppi_differential_drive.py:201-249: one `prev_way_point_idx`
-// threaded through all K (T+1) cost calls in k-major order).  Every call is a map p -> g(p) = first nearest waypoint
-// in [p, p+20); a sample is the composition of its T+1 maps, a workgroup of its 16 samples', an iteration of its
-// workgroups'.  The index only moves forward and, per iteration, by a handful of waypoints, so the maps are tabulated
-// on the HYP_R entry indices c .. c+HYP_R-1 (c = the x0 call's index): the rollout launch leaves, per workgroup, the
-// map and one softmin record PER ENTRY INDEX; the finalize kernel composes the 256 maps (a chain of table lookups)
-// and merges the records of the realised entries.  A chain that leaves the table (HYP_OVF) falls back to the
-// speculation rounds from that workgroup on, so the result is exact either way.
-constexpr int HYP_R = 16, HYP_WINDOW = 20, HYP_WINDOW_CUDA = 10, HYP_CAND = HYP_R + HYP_WINDOW - 1, HYP_OVF = 255;
-constexpr int HYP_MAX_BLOCKS = 256;  // workgroups whose maps one finalize block composes
+// threaded through all K (T+1) cost calls in k-major order, each call `p <- first nearest waypoint in [p, p+W)`).
+// Where a call's distances to the candidates behind c first fall strictly and then never fall again -- a position
+// beside a path that does not fold back within the candidates -- its first minimum over ALL of them is m = the number
+// of descents, and the search entered at any p returns max(p, m) (p <= m: m is the first minimum of [p, p+W) as long
+// as m - p < W; p > m: nothing behind p is smaller).  The threaded index is then a running maximum of the calls' m in
+// call order: a wave reduction per sample, a row reduction per workgroup, and across workgroups a decoupled look-back
+// on one word per workgroup (fused_lookback) -- every sample is priced once, with its exact index, in the one rollout
+// launch, and k_finalize only reads the largest offset.  LB_CAND candidates are examined: exact while every realised
+// index p keeps [p, p+W) inside them (p <= LB_CAND - W, or the path ends inside them) and below W; a call that is not
+// unimodal, an index beyond that reach or a look-back that times out sets the `bad` bit of the workgroup's word, and
+// k_finalize hands the iteration to the speculation rounds (exact either way).
+// Word of workgroup b: [31:8] iteration tag, [7] bad, [6:0] largest offset of the workgroup's own calls.
+constexpr int HYP_WINDOW = 20, HYP_WINDOW_CUDA = 10;  // the search windows of the reference's files
+constexpr int LB_CAND = 32, LB_BAD = 0x80;
+constexpr unsigned LB_TAG_MASK = 0xffffff00u;
+constexpr unsigned long long LB_TIMEOUT_TICKS = 20000ull;  // 200 us at 100 MHz
+constexpr int HYP_MAX_BLOCKS = 256;  // workgroups whose words one finalize wave reads (four per lane)
+__host__ __device__ inline unsigned lb_tag(long long iter) { return ((unsigned)(iter + 1) & 0xffffffu) << 8; }
 
 // Controller state that lives on the device (so closed loops need no host round trip).
 struct DevState {
@@ -50,7 +59,7 @@ struct DevState {
 struct StepResult {
     int status, k_next, c_next, idx_start;
     int idx_after, path_end, rounds;
-    int costs_hyp;  // the iteration ended in the one-launch resolution: S[k] = hyp_S[k / 16][hyp_q[k / 16]][k % 16]
+    int costs_hyp;  // the iteration's sequential index was resolved in its one rollout launch (fused_lookback)
     int n_collided, pad_res;  // samples of this handle whose cost carries a collision penalty (-1: records of other ranks merged)
     long long iter;
     double rho, eta, ess;
@@ -111,12 +120,10 @@ template <typename R> struct KParams {
     // MPPI_WAYPOINT_PER_ROLLOUT: the index threads through a sample's own cost calls (as `sequential` threads it through
     // all samples' calls) and starts from the x0 call's index at every sample: samples stay independent
     int per_rollout, pad_pr;
-    // one-launch resolution of the sequential index (see HYP_R): per workgroup b and entry index q
-    int hyp;                // the handle qualifies (fused layout, T <= 64, window 20, `S[k] =`, one agent, <= 256 workgroups)
-    R *hyp_rec;             // [blocks][HYP_R][record_len]  softmin record of workgroup b entered at c + q
-    R *hyp_heads;           // [blocks][HYP_R][4]
-    unsigned char *hyp_map; // [blocks][HYP_R]               index offset the workgroup leaves behind (HYP_OVF: left the table)
-    R *hyp_S;               // [blocks][HYP_R][16]           the samples' costs under that entry
+    // one-launch resolution of the sequential index (see LB_CAND)
+    int hyp;                // the handle qualifies (fused layout, T <= 64, window 20 / 10, `S[k] =`, one agent, <= 256 workgroups)
+    int pad_hyp;
+    unsigned *hyp_slots;    // [HYP_MAX_BLOCKS] one word per workgroup
 };
 
 struct FinalizeParams {
@@ -150,12 +157,9 @@ struct FinalizeParams {
     // several agents per launch (blockIdx.y), see KParams
     int slots, n_agents;
     size_t res_stride;       // bytes between two agents' StepResult (+ returned u)
-    // one-launch resolution of the sequential index (see HYP_R / KParams)
+    // one-launch resolution of the sequential index (see LB_CAND / KParams)
     int hyp, hyp_blocks;
-    const void *hyp_rec, *hyp_heads, *hyp_S;
-    const unsigned char *hyp_map;
-    unsigned char *hyp_q;    // [blocks] the entry offset each workgroup was realised with (kept for mppi_get_costs)
-    void *S;                 // [K] handle precision: costs of the samples resolved before a chain left the table
+    const unsigned *hyp_slots;
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights
@@ -209,9 +213,6 @@ void launch_merge(const void *recs, const void *heads, int n, int group, int T, 
 template <typename R> void launch_finalize(const FinalizeParams &F, bool recs_f64, hipStream_t s);
 // exchange self-test: one flag round over the peers, no records
 void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s);
-// S[k] of an iteration that ended in the one-launch resolution (StepResult::costs_hyp)
-template <typename R>
-void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K, hipStream_t s);
 // batched stage methods (mppi_eval_*): `what` of launch_eval
 enum { EVAL_TRANSITION = 0, EVAL_COST_STAGE = 1, EVAL_COST_TERMINAL = 2, EVAL_COLLIDED = 3, EVAL_CLAMP = 4 };
 template <typename R>

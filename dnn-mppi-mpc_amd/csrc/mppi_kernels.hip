@@ -29,9 +29,10 @@ template <typename R> struct alignas(4 * sizeof(R)) VecT4 { R x, y, z, w; };
 // Diagnostic build only (make stamps): wall-clock stamps (s_memrealtime, 10 ns ticks) of block 0 / wave 0
 // at phase boundaries, written to a buffer nothing else reads.  The shipped library has no stamps.
 #ifdef MPPI_STAMPS
-__device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_stamps[128];  // [64 + n]: the same stamp of the LAST workgroup of the launch
 #define STAMP(n)                                                                 \
     do {                                                                         \
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_stamps[64 + (n)] = wall_clock64(); \
         if (blockIdx.x == 0 && threadIdx.x == 0) {                               \
             g_stamps[n] = wall_clock64();                                        \
             if ((n) < 8) g_stamps[40 + (n)] = clock64(); /* shader clock ticks */ \
@@ -381,129 +382,190 @@ template <int N> __device__ __forceinline__ void publish_first_mover(const int *
 }
 
 // ------------------------------------------------------------------------------------------
-// The sequential waypoint index in ONE launch (HYP_R in mppi_kernels.h; mppi_differential_drive.py:201-249).
-// Every wave tabulates its sample's T+1 calls as maps on the HYP_R entry offsets, composes them (lanes over the entry
-// offset, a chain of LDS byte reads split over four lane groups), and prices the sample under every entry; the
-// workgroup chains its 16 samples the same way and leaves, PER ENTRY OFFSET Q, its map value, the samples' costs and a
-// softmin record.  k_finalize composes the workgroups' maps and merges the records of the realised entries.
-// `S[k] =` semantics only (:124): the cost needs the index of the last stage call and of the terminal call.
+// The sequential waypoint index in ONE launch (LB_CAND in mppi_kernels.h; mppi_differential_drive.py:201-249).
+// Pass A: every lane counts the strict descents of its call's distances over the LB_CAND candidates behind c and checks
+// that none follows a non-descent (then the count IS the first nearest candidate m, and a search entered at any p
+// returns max(p, m)); the wave's and the workgroup's maxima follow, the workgroup publishes its maximum in its slot.
+// Look-back: wave 0 waits for the slots of all workgroups before its own (they were dispatched earlier and wait for
+// nothing behind them) and takes their maximum E -- the offset this workgroup is entered at.  Meanwhile every wave
+// prices its sample under every offset (lanes over the offset).  Pass B: sample w's index is max(E, the samples before it,
+// its own) -- `S[k] =` semantics only (:124): the cost needs the index of the last stage call and of the terminal call,
+// which searches from the same state and so stays where the last stage call left it.
+// A call that is not unimodal, an index that leaves the candidates' reach or a wait that times out raises the slot's
+// `bad` bit: k_finalize hands the iteration to the speculation rounds.  Returns S_k; lane 0 stores S and pout.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {  // a wave reads what its own lanes have just written to LDS
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// pass A of one pair of candidates {x_2q, x_2q+1, y_2q, y_2q+1}: does this lane's distance fall at the first / the second
+// of them (f32: two packed subtractions, a packed product and a packed fma)
+typedef float lb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lb_pair(const RefPair<float> &rp, float x, float y, float &prev, bool &g0, bool &g1) {
+    const lb_f2 dx = lb_f2{x, x} - lb_f2{rp.x0, rp.x1}, dy = lb_f2{y, y} - lb_f2{rp.y0, rp.y1};
+    const lb_f2 d = dx * dx + dy * dy;
+    g0 = d.x < prev;
+    g1 = d.y < d.x;
+    prev = d.y;
+}
+__device__ __forceinline__ void lb_pair(const RefPair<double> &rp, double x, double y, double &prev, bool &g0, bool &g1) {
+    const double dx0 = x - rp.x0, dx1 = x - rp.x1, dy0 = y - rp.y0, dy1 = y - rp.y1;
+    const double d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+    g0 = d0 < prev;
+    g1 = d1 < d0;
+    prev = d1;
 }
 
+// Returns, on lane l, S of the workgroup's sample l & 15 (every wave computes all sixteen); lane 0 stores S_k and pout.
 template <typename R, bool OBS, bool PLAIN>
-__device__ __forceinline__ void fused_hyp(const KParams<R> &P, const DevState &sv) {
-    __shared__ RefPair<R> sh_win[(HYP_CAND + 1) / 2];
-    __shared__ __attribute__((aligned(16))) unsigned char sh_g[FUSED_WAVES][64][HYP_R];
-    __shared__ unsigned char sh_seg[FUSED_WAVES][4][HYP_R];
-    __shared__ unsigned char sh_M[FUSED_WAVES][HYP_R];
-    __shared__ R sh_Sq[FUSED_WAVES][HYP_R];  // sample w priced with ITSELF entered at offset q
-    __shared__ R sh_SQ[FUSED_WAVES][HYP_R];  // sample w priced with the WORKGROUP entered at offset Q
-    __shared__ R sh_e[FUSED_WAVES][HYP_R];
-    __shared__ R sh_eps[FUSED_WAVES][128];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, q = lane & (HYP_R - 1);
-    const int k = blockIdx.x * FUSED_WAVES + wid;  // wave-uniform
-    const bool valid = k < P.K;
-    const int c = sv.c, T = P.T;
-    hyp_stage_window(sh_win, P.ref, c, P.n_ref, (int)threadIdx.x, P.window);
+__device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState &sv, int k, bool valid_in, float &e0, float &e1) {
+    __shared__ RefPair<R> sh_c[LB_CAND / 2];
+    __shared__ VecT4<R> sh_row[LB_CAND];          // the candidates' rows {x, y, yaw, v}: what the costs are taken against
+    __shared__ R sh_cost[FUSED_WAVES][LB_CAND];   // sample w priced under offset j
+    __shared__ int sh_M[FUSED_WAVES];
+    __shared__ int sh_E;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool valid = __builtin_amdgcn_readfirstlane((int)valid_in) != 0;  // (wave-uniform: said so that the counting below stays scalar)
+    const int c = sv.c, b = blockIdx.x;
+    const int nc = min(LB_CAND, P.n_ref - c);  // (> 1: the caller's condition)
+    const unsigned tag = lb_tag(sv.iter);
+    // thread j < LB_CAND fetches candidate j's row (an absent one: far away, it never descends); the loads are in flight
+    // during the draw
+    VecT4<R> mine{R(1e30), R(1e30), R(0), R(0)};
+    if ((int)threadIdx.x < nc) mine = *reinterpret_cast<const VecT4<R> *>(P.ref + 4 * (c + (int)threadIdx.x));
     const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
+    Rollout<R, MODEL_DIFF, OBS, PLAIN> r(P, sv, k, lane, nullptr, obs, 0);
+    typename Rollout<R, MODEL_DIFF, OBS, PLAIN>::Step sp{R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0), false};
+    if (valid) sp = r.dynamics(0, e0, e1);
+    if (threadIdx.x < LB_CAND) {
+        const int j = threadIdx.x;
+        sh_row[j] = mine;
+        R *pair = reinterpret_cast<R *>(&sh_c[j >> 1]);  // {x_2q, x_2q+1, y_2q, y_2q+1}
+        pair[j & 1] = mine.x;
+        pair[2 + (j & 1)] = mine.y;
+    }
     __syncthreads();
-    float e0 = 0.f, e1 = 0.f;
-    int M = q;                // the sample's map at entry offset q (an absent sample: identity)
-    R Sq = R(INFINITY);       // its cost entered at q
+    int Mw = 0;
+    bool bad_w = false;
     if (valid) {
-        Rollout<R, MODEL_DIFF, OBS, PLAIN> r(P, sv, k, lane, nullptr, obs, 0);
-        const auto sp = r.dynamics(0, e0, e1);
-        const HypTable g = hyp_table(sh_win, sp.x, sp.y, P.window);
-        *reinterpret_cast<HypTable *>(&sh_g[wid][lane][0]) = g;
-        wave_lds_sync();
-        // compose the T stage calls: lane group s chains calls [s Ts, (s+1) Ts) from every entry offset, then the
-        // four partial maps are chained
-        const int seg = lane >> 4, Ts = (T + 3) >> 2, tb = seg * Ts, te = min(T, tb + Ts);
-        int p = q;
-        for (int t = tb; t < te; ++t) p = p < HYP_R ? (int)sh_g[wid][t][p] : HYP_OVF;
-        sh_seg[wid][seg][q] = (unsigned char)p;
-        wave_lds_sync();
-        p = q;
+        // ---- pass A: this lane's call (the state after step `lane`) against the candidates, in pairs ------------
+        // Per candidate a comparison and a count per lane; that every lane's descents come first is checked on the lane
+        // masks (scalar unit): the sets of descending lanes must shrink from candidate to candidate.  An idle lane
+        // compares NaNs: it never descends.
+        const R x = sp.act ? sp.x : R(NAN), y = sp.y;
+        unsigned long long last = ~0ull, bad = 0ull;
+        int m = -1;  // (candidate 0 is compared against +inf: counted off here)
+        R prev = R(INFINITY);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) p = p < HYP_R ? (int)sh_seg[wid][s4][p] : HYP_OVF;
-        const int a_stage = p;                                                      // the last stage call's index (:228)
-        const int a_term = p < HYP_R ? (int)sh_g[wid][T - 1][p] : HYP_OVF;          // the terminal call: same state (:244)
-        // the state after the last step and its control cost, held by lane T-1
-        const int ll = r.lane_last;
-        const R xT = wv::read_lane(sp.x, ll), yT = wv::read_lane(sp.y, ll), yawT = wv::read_lane(sp.yaw, ll);
-        const R ctrl = (sp.u0 * P.sinv[0] + sp.u1 * P.sinv[2]) * sp.v0 + (sp.u0 * P.sinv[1] + sp.u1 * P.sinv[3]) * sp.v1;  // :124
-        const R ctrlT = wv::read_lane(ctrl, ll);
-        const bool hit_lane = OBS ? collided<false>(P, sp.x, sp.y, sp.yaw, obs) : false;
-        const bool hitT = OBS ? ((__ballot(hit_lane) >> ll) & 1ull) != 0ull : false;
-        if (a_stage < HYP_R && a_term < HYP_R) {
-            R st_c = tracking_cost<R, MODEL_DIFF>(P, P.ws, r.wrap_stage(), c + a_stage, xT, yT, yawT, R(0));
+        for (int q0 = 0; q0 < LB_CAND / 2; q0 += 4) {
+            RefPair<R> rp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rp[i] = sh_c[q0 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bool g0, g1;
+                lb_pair(rp[i], x, y, prev, g0, g1);
+                m += (g0 ? 1 : 0) + (g1 ? 1 : 0);
+                const unsigned long long b0 = __ballot(g0), b1 = __ballot(g1);
+                bad |= (b0 & ~last) | (b1 & ~b0);
+                last = b1;
+            }
+        }
+        if (!sp.act) m = 0;
+        Mw = wv::reduce<wv::OpMaxInt>(m);
+        bad_w = bad != 0ull;
+    }
+    STAMP(11);
+    if (lane == 0) sh_M[wid] = Mw | (bad_w ? LB_BAD : 0);
+    __syncthreads();
+    STAMP(12);
+    // the workgroup's maximum and, for wave w, the maximum of the samples before it (one DPP row of 16 values)
+    static_assert(FUSED_WAVES == 16, "one DPP row of maxima");
+    const int mv = sh_M[lane & 15];
+    const int incl = wv::scan_incl_row<wv::OpMaxInt>(mv & (LB_BAD - 1));
+    const int Mb = wv::read_lane(incl, 15);
+    const bool bad_b = (__ballot((mv & LB_BAD) != 0) & 0xffffull) != 0ull;
+    unsigned *slots = P.hyp_slots;
+    if (wid == 0 && lane == 0)
+        __hip_atomic_store(&slots[b], tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- this sample priced under every offset, lanes over the offset (wave 0: while its word travels) -----------
+    {
+        R cost_j = R(INFINITY);
+        if (valid) {  // (every lane takes part in the ballot and the lane reads; lanes >= LB_CAND price the last candidate again)
+            const int ll = r.lane_last;
+            const R xT = wv::read_lane(sp.x, ll), yT = wv::read_lane(sp.y, ll), yawT = wv::read_lane(sp.yaw, ll);
+            const R ctrl = (sp.u0 * P.sinv[0] + sp.u1 * P.sinv[2]) * sp.v0 + (sp.u0 * P.sinv[1] + sp.u1 * P.sinv[3]) * sp.v1;  // :124
+            const R ctrlT = wv::read_lane(ctrl, ll);
+            const bool hit_lane = OBS ? collided<false>(P, sp.x, sp.y, sp.yaw, obs) : false;
+            const bool hitT = OBS ? ((__ballot(hit_lane) >> ll) & 1ull) != 0ull : false;
+            const VecT4<R> row = sh_row[min(lane, nc - 1)];
+            const R rr[4] = {row.x, row.y, row.z, row.w};
+            R st_c = tracking_cost_row<R, MODEL_DIFF>(P, P.ws, r.wrap_stage(), rr, xT, yT, yawT, R(0));
             if (hitT) st_c += P.penalty;
             const R stage = st_c + P.gamma * ctrlT;
-            R term = tracking_cost<R, MODEL_DIFF>(P, P.wt, r.wrap_term(), c + a_term, xT, yT, yawT, R(0));
+            R term = tracking_cost_row<R, MODEL_DIFF>(P, P.wt, r.wrap_term(), rr, xT, yT, yawT, R(0));
             if (hitT) term += P.penalty;
-            Sq = stage + term;
-            M = a_term;
-        } else {
-            M = HYP_OVF;  // the index leaves the table: this entry is resolved by the speculation rounds instead
+            cost_j = stage + term;
         }
+        if (lane < LB_CAND) sh_cost[wid][lane] = cost_j;
     }
-    if (lane < HYP_R) {
-        sh_M[wid][lane] = (unsigned char)M;
-        sh_Sq[wid][lane] = Sq;
-    }
-    sh_eps[wid][2 * lane] = (R)e0;
-    sh_eps[wid][2 * lane + 1] = (R)e1;
-    __syncthreads();
-    // the offset this sample is entered at when the WORKGROUP is entered at Q = q: through the samples before it
-    int ent = q;
-    for (int j = 0; j < wid; ++j) ent = ent < HYP_R ? (int)sh_M[j][ent] : HYP_OVF;
-    const R SQ = ent < HYP_R ? sh_Sq[wid][ent] : R(INFINITY);
-    const int after = ent < HYP_R ? (int)sh_M[wid][ent] : HYP_OVF;  // (the last wave's: what the workgroup leaves)
-    if (lane < HYP_R) sh_SQ[wid][lane] = SQ;
-    __syncthreads();
-    R rho = sh_SQ[0][q];
+    STAMP(14);
+    if (wid == 0) {
+        // ---- look-back: the words of the workgroups before this one, four per lane and load ----------------------
+        int E = 0;
+        bool bad_e = false;
+        if (b > 0) {
+            static_assert(HYP_MAX_BLOCKS <= 256, "one 16-byte load per lane covers the words");
+            unsigned long long t0 = 0ull;
+            for (int n = 0;; ++n) {
+                bool ready = true, bd = false;
+                int mx = 0;
+                if (4 * lane < b) {
+                    // (volatile: a load that bypasses this XCD's L2 -- the words come from the other XCDs' workgroups)
+                    typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
+                    const lb_u4 w4 = *((const volatile __attribute__((address_space(1))) lb_u4 *)slots + lane);
+                    const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-    for (int w = 1; w < FUSED_WAVES; ++w) rho = fmin(rho, sh_SQ[w][q]);
-    const R e = SQ < R(INFINITY) ? mf::exp_(-P.beta * (SQ - rho)) : R(0);  // :175
-    if (lane < HYP_R) sh_e[wid][lane] = e;
-    __syncthreads();
-    const size_t b = blockIdx.x;
-    const int rlen = record_len(T, (int)sizeof(R));
-    {   // W_b(Q)[i] = sum_k e_k(Q) eps[k, i] (:132-135): thread = (column i, a pair of entry offsets)
-        const int i = threadIdx.x & 127, Q0 = 2 * ((int)threadIdx.x >> 7);
-        if (i < 2 * T) {
-            R a0 = 0, a1 = 0;
-#pragma unroll
-            for (int w = 0; w < FUSED_WAVES; ++w) {
-                const R ev = sh_eps[w][i];
-                a0 += sh_e[w][Q0] * ev;
-                a1 += sh_e[w][Q0 + 1] * ev;
+                    for (int j = 0; j < 4; ++j) {
+                        if (4 * lane + j < b) {
+                            ready &= (w[j] & LB_TAG_MASK) == tag;
+                            bd |= (w[j] & LB_BAD) != 0u;
+                            mx = max(mx, (int)(w[j] & (LB_BAD - 1)));
+                        }
+                    }
+                }
+                if (__ballot(!ready) == 0ull) {
+                    E = wv::reduce<wv::OpMaxInt>(mx);
+                    bad_e = __ballot(bd) != 0ull;
+                    break;
+                }
+                // (the clock is a memory round trip of its own: looked at every 16th poll only)
+                if ((n & 15) == 15) {
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0ull) t0 = now;
+                    if (now - t0 > LB_TIMEOUT_TICKS) {  // (never seen; the iteration is redone by the speculation rounds)
+                        bad_e = true;
+                        break;
+                    }
+                }
             }
-            P.hyp_rec[(b * HYP_R + Q0) * rlen + 4 + i] = a0;
-            P.hyp_rec[(b * HYP_R + Q0 + 1) * rlen + 4 + i] = a1;
         }
+        // the offsets this workgroup's calls were entered at stay within the candidates' reach (see LB_CAND)
+        const int leave = max(E, Mb);
+        const bool reach = leave < P.window && (leave + P.window <= LB_CAND || P.n_ref - c <= LB_CAND);
+        if ((bad_e || !reach) && !bad_b && lane == 0) __hip_atomic_fetch_or(&slots[b], (unsigned)LB_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) sh_E = E;
+        STAMP(13);
     }
-    if (lane < HYP_R) P.hyp_S[(b * HYP_R + lane) * FUSED_WAVES + wid] = SQ;
-    if (wid == FUSED_WAVES - 1 && lane < HYP_R) {
-        R eta = 0, eta2 = 0, n_hit = 0;
-#pragma unroll
-        for (int w = 0; w < FUSED_WAVES; ++w) {
-            const R ew = sh_e[w][lane];
-            eta += ew;
-            eta2 += ew * ew;
-            if (OBS) n_hit += (sh_SQ[w][lane] >= P.penalty && sh_SQ[w][lane] < R(INFINITY)) ? R(1) : R(0);
-        }
-        R *out = P.hyp_rec + (b * HYP_R + lane) * rlen;
-        out[0] = rho;
-        out[1] = eta;
-        out[2] = eta2;
-        *reinterpret_cast<VecT4<R> *>(P.hyp_heads + 4 * (b * HYP_R + lane)) = VecT4<R>{rho, eta, eta2, n_hit};
-        P.hyp_map[b * HYP_R + lane] = (unsigned char)after;
+    __syncthreads();
+    STAMP(15);
+    // ---- pass B: every wave prices all sixteen samples (lane l: sample l & 15) -- no second exchange of costs -------
+    const int E = sh_E;
+    const int w15 = lane & 15;
+    const int before_l = wv::dpp<wv::DPP_ROW_SHR1>(incl, 0);  // the samples before sample l & 15 (row-wise shift; 0 for the first)
+    const int a = min(max(max(E, before_l), mv & (LB_BAD - 1)), nc - 1);
+    const R S_l = sh_cost[w15][a];
+    if (valid && lane == wid) {  // (lane wid holds this wave's own sample)
+        P.S[k] = S_l;
+        P.pout[k] = c + a;
     }
+    return S_l;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -583,17 +645,15 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     STAMP(1);
     const bool valid = k < P.K;
     const int wlen0 = window_len<R>(P.window, P.n_ref, sv.c);
-    if (HYPK) {
-        // the first round of an iteration whose waypoint index can move: every entry index at once (fused_hyp)
-        if (sv.round == 0 && wlen0 > 1) return fused_hyp<R, OBS, PLAIN>(P, sv);
-    }
+    // HYPK, the first round of an iteration whose waypoint index can move: resolved in this launch (fused_lookback)
+    const bool lookback = HYPK && sv.round == 0 && wlen0 > 1;
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = OBS ? load_obstacles(P, lane) : ObsLanes<R>{R(0), R(0), R(0)};
     // Both waypoint modes search the window at c first.  A window of ONE candidate (the robot holds the end of the
     // path) leaves nothing to search or to move: no staging and no barrier behind its loads then (0.7 us per launch
     // at config 2).
-    const bool seq_search = P.sequential && wlen0 > 1;
-    const bool use_win = wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
+    const bool seq_search = !lookback && P.sequential && wlen0 > 1;
+    const bool use_win = !lookback && wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
     __shared__ int sh_mover[FUSED_WAVES];
     __shared__ int sh_first;
     if (use_win) stage_window(sh_win, P.ref, sv.c, wlen0, (int)threadIdx.x, (int)blockDim.x);
@@ -607,7 +667,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
     // MPPI_WAYPOINT_PER_ROLLOUT on horizons of one chunk: positions -> LDS, four waves thread the indices, costs (see
     // per_rollout_thread); a window of one candidate leaves nothing to thread
     const bool pr_fast = !PLAIN && NCH == 1 && P.per_rollout && wlen0 > 1 && P.n_ref < 32768;
-    if (pr_fast) {
+    R S_all = R(INFINITY);  // (look-back: every wave holds all sixteen costs, sample l & 15 on lane l)
+    if (lookback) {
+        if constexpr (HYPK && MODEL == MODEL_DIFF && NCH == 1) S_all = fused_lookback<R, OBS, PLAIN>(P, sv, k, valid, e0[0], e1[0]);
+        S_k = wv::read_lane(S_all, wid);
+    } else if (pr_fast) {
         __shared__ R sh_px[FUSED_WAVES][64], sh_py[FUSED_WAVES][64];
         __shared__ short sh_ix[FUSED_WAVES][66];
         __shared__ R sh_pref[2 * PR_REF_LDS];
@@ -642,16 +706,19 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_rollout_fused(const DevSta
         }
     }
     STAMP(2);
-    if (lane == 0) {
-        sh_S[wid] = S_k;
-        if (seq_search) sh_mover[wid] = mover;
+    R sv_l = S_all;
+    if (!lookback) {
+        if (lane == 0) {
+            sh_S[wid] = S_k;
+            if (seq_search) sh_mover[wid] = mover;
+        }
+        __syncthreads();
+        sv_l = sh_S[lane & 15];
     }
-    __syncthreads();
     STAMP(3);
     // rho_b = min over the workgroup's 16 costs: lane w of a row reads sample w's, four DPP steps fold the row (every wave
     // needs it: 16 reads + 15 minima per wave took a twelfth of the launch's VALU instructions)
     static_assert(FUSED_WAVES == 16, "one DPP row of costs");
-    const R sv_l = sh_S[lane & 15];
     const R rho = wv::read_lane(wv::scan_incl_row<wv::OpMin>(sv_l), 15);
     // (samples whose cost carries a collision penalty, mppi_stats::n_collided: one ballot over the costs read above)
     const int n_hit_i = OBS ? __popcll(__ballot(sv_l >= P.penalty && sv_l < R(INFINITY)) & 0xffffull) : 0;
@@ -1329,14 +1396,6 @@ __global__ __launch_bounds__(256) void k_reduce(const KParams<R> P, R *__restric
     }
 }
 
-// S[k] of an iteration that ended in the one-launch resolution of the sequential index (fused_hyp): workgroup b was
-// realised with entry offset hyp_q[b]
-template <typename R>
-__global__ void k_gather_costs(const R *__restrict__ hyp_S, const unsigned char *__restrict__ hyp_q, R *__restrict__ S, int K) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < K) S[k] = hyp_S[((size_t)(k >> 4) * HYP_R + hyp_q[k >> 4]) * 16 + (k & 15)];
-}
-
 // normalised weights of the last iteration (`_compute_weight` :167-180), for inspection
 template <typename R>
 __global__ void k_weights(const R *__restrict__ S, int K, double beta, double rho, double eta, double *w) {
@@ -1469,16 +1528,13 @@ template <typename A, int NT = MERGE_THREADS, int NWIN = 1> struct MergeRegs {
     A hc[4 * NWIN];                                // their fourth word: samples that carry a collision penalty
 };
 
-// `sel` (LDS, one byte per record): record b is entry sel[b] of workgroup b's HYP_R records (fused_hyp) -- the stride
-// between workgroups is HYP_R records then
 template <typename A, int NT, int NWIN>
-__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT, NWIN> &m,
-                                                 const unsigned char *sel = nullptr) {
+__device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, MergeRegs<A, NT, NWIN> &m) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 4 * NWIN; ++i) {  // the compact copy: consecutive lanes read consecutive 16 / 32 bytes
         const int b = lane + 64 * i;
-        const size_t r = sel ? (size_t)b * HYP_R + min((int)sel[b], HYP_R - 1) : (size_t)b;
+        const size_t r = (size_t)b;
         const VecT4<A> hd = *reinterpret_cast<const VecT4<A> *>(heads + 4 * r);
         m.hr[i] = hd.x;
         m.he[i] = hd.y;
@@ -1488,23 +1544,13 @@ __device__ __forceinline__ void merge_load_heads(const A *__restrict__ heads, Me
 }
 
 template <typename A, int NT, int NWIN>
-__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT, NWIN> &m,
-                                                const unsigned char *sel = nullptr) {
+__device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int T, int vt, MergeRegs<A, NT, NWIN> &m) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ;
     const int tid = threadIdx.x, vc = tid & 31, grp = tid >> 5;
     const unsigned rbytes = (unsigned)record_len(T, (int)sizeof(A)) * (unsigned)sizeof(A);
     const int nvc = (2 * T + VW - 1) / VW;  // 16-byte columns of W
     const char *base = reinterpret_cast<const char *>(recs);
     const unsigned col = (unsigned)(4 + min(vt * 32 + vc, nvc - 1) * VW) * (unsigned)sizeof(A);
-    if (sel) {  // (NWIN == 1: the one-launch resolution serves up to HYP_MAX_BLOCKS = 256 workgroups)
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int b = grp * MAXJ + j;
-            const unsigned r = (unsigned)b * HYP_R + (unsigned)min((int)sel[b], HYP_R - 1);
-            m.w[0][j] = *reinterpret_cast<const VecT<A> *>(base + (size_t)r * rbytes + col);
-        }
-        return;
-    }
     const unsigned off0 = (unsigned)(grp * MAXJ) * rbytes + col;
 #pragma unroll
     for (int win = 0; win < NWIN; ++win)
@@ -1517,7 +1563,7 @@ __device__ __forceinline__ void merge_load_tile(const A *__restrict__ recs, int 
 template <typename A, int NT, int NWIN, typename Store>
 __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n, int T, A beta,
                                               MergeRegs<A, NT, NWIN> &m, A *sh_s, A *sh_part, A &rho, A &eta, A &eta2,
-                                              Store store, const unsigned char *sel = nullptr, A *n_hit = nullptr) {
+                                              Store store, A *n_hit = nullptr) {
     constexpr int VW = 16 / sizeof(A), MAXJ = MergeShape<NT>::MAXJ, GROUPS = MergeShape<NT>::GROUPS;
     using V = VecT<A>;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1578,7 +1624,7 @@ __device__ __forceinline__ void merge_combine(const A *__restrict__ recs, int n,
         if (vt > 0) __syncthreads();  // the previous tile's readers of sh_part are done
         *reinterpret_cast<V *>(sh_part + (grp * 32 + vc) * VW) = acc;
         __syncthreads();
-        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT, NWIN>(recs, T, vt + 1, m, sel);  // T > 64 (f64: 32) only
+        if (__builtin_expect(vt + 1 < n_tiles, 0)) merge_load_tile<A, NT, NWIN>(recs, T, vt + 1, m);  // T > 64 (f64: 32) only
         for (int e = tid; e < 32 * VW; e += NT) {
             const int i = vt * 32 * VW + e;
             if (i < 2 * T) {
@@ -1634,7 +1680,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge(const A *__restrict__ r
     merge_load_heads<A, MERGE_THREADS, 1>(heads + 4 * (size_t)b0, mr);
     merge_load_tile<A, MERGE_THREADS, 1>(mine, T, 0, mr);
     A rho, eta, eta2, n_hit = 0;
-    merge_combine<A, MERGE_THREADS, 1>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; }, nullptr, &n_hit);
+    merge_combine<A, MERGE_THREADS, 1>(mine, nb, T, beta, mr, L.s, L.part, rho, eta, eta2, [&](int i, A v) { sh_w[i] = v; }, &n_hit);
     // merge_combine leaves W / eta; a record carries W itself
     if (ABI_OUT) {
         double *o = reinterpret_cast<double *>(out) + (size_t)blockIdx.x * partial_len(T);
@@ -1755,15 +1801,10 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     unsigned long long peer_ptr = 0;
     if (XCHG) peer_ptr = load_peer_ptrs(F);
     MergeRegs<A, NT, NWIN> mr;
-    // (HYPK: which records there are to merge -- the compact ones or the realised entries of the one-launch resolution --
-    // is known once the state is here; wave 0 fetches the workgroups' maps meanwhile, four per lane)
-    uint4 hmap[4] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
-    if (HYPK) {
-        if (wid == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hmap[j] = reinterpret_cast<const uint4 *>(F.hyp_map)[4 * lane + j];
-        }
-    } else if (!ABI_RECS) {
+    // (HYPK: wave 0 fetches the workgroups' look-back words as well, four per lane)
+    uint4 hwords = uint4{0, 0, 0, 0};
+    if (HYPK && wid == 0) hwords = reinterpret_cast<const uint4 *>(F.hyp_slots)[lane];
+    if (!ABI_RECS) {
         merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
         merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
     }
@@ -1812,74 +1853,41 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         if (tid == 0) { res->status = STATUS_EXCHANGE_FAILED; res->iter = iter; }
         return leave();
     }
-    // --- the sequential index resolved in this launch: compose the workgroups' maps (fused_hyp) -----------------
+    // --- the sequential index resolved in the rollout launch (fused_lookback): the largest offset any workgroup saw ----
     int c_final = c_state;
     bool hyp_done = false;
-    const unsigned char *sel = nullptr;  // != null: the records to merge are the realised entries of the HYP_R per workgroup
     if (HYPK) {  // (launched with the HYPK rollout kernel: the same condition there)
         static_assert(!HYPK || (MODE == 0 && NWIN == 1 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
         const bool hyp_round = round == 0 && min(F.window, F.n_ref - c_state) > 1;
-        if (!hyp_round) {  // a speculation round, or nothing can move: the compact records as in the lean kernel
-            merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
-            merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
-        } else {
-            unsigned char *sh_q = reinterpret_cast<unsigned char *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));  // [256]
-            int *sh_i = reinterpret_cast<int *>(sh_q + HYP_MAX_BLOCKS);  // {first workgroup that leaves the table, final offset}
-            const int nb = F.hyp_blocks;
+        if (hyp_round) {
+            int *sh_i = reinterpret_cast<int *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));  // {bad, largest offset}
             if (wid == 0) {
-                // Compose the workgroups' maps from offset 0 (the x0 call's index).  Nearly all of them leave the offset
-                // they are entered at unchanged, so: every lane looks its four maps up at the current offset p, the first
-                // workgroup whose value differs takes p there, and again from the workgroup behind it -- one trip per
-                // workgroup that moves the index (a handful per iteration), no memory access inside.
-                int qv[4] = {0, 0, 0, 0};
-                int p = 0, start = 0, ovf = INT_MAX;
-                for (;;) {
-                    int nxt[4];
-                    bool mv[4];
-                    const int pw = p >> 2, ps = 8 * (p & 3);
+                const unsigned tag = lb_tag(iter);
+                const unsigned hw[4] = {hwords.x, hwords.y, hwords.z, hwords.w};
+                int mx = 0;
+                bool bd = false;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned w4 = pw == 0 ? hmap[j].x : pw == 1 ? hmap[j].y : pw == 2 ? hmap[j].z : hmap[j].w;
-                        nxt[j] = (int)((w4 >> ps) & 255u);
-                        const int b = 4 * lane + j;
-                        if (b >= start) qv[j] = p;
-                        mv[j] = b >= start && b < nb && nxt[j] != p;
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * lane + j < F.hyp_blocks) {
+                        bd |= (hw[j] & LB_TAG_MASK) != tag || (hw[j] & LB_BAD) != 0u;
+                        mx = max(mx, (int)(hw[j] & (LB_BAD - 1)));
                     }
-                    const unsigned long long m = __ballot(mv[0] | mv[1] | mv[2] | mv[3]);
-                    if (m == 0ull) break;
-                    const int fl = __builtin_ctzll(m);
-                    const int jf = mv[0] ? 0 : mv[1] ? 1 : mv[2] ? 2 : 3;
-                    const int nf = mv[0] ? nxt[0] : mv[1] ? nxt[1] : mv[2] ? nxt[2] : nxt[3];
-                    const int bf = 4 * fl + __builtin_amdgcn_readlane(jf, fl), pn = __builtin_amdgcn_readlane(nf, fl);
-                    if (pn >= HYP_R) {  // (HYP_OVF) workgroup bf's chain leaves the table from its entry p
-                        ovf = bf;
-                        break;
-                    }
-                    p = pn;
-                    start = bf + 1;
                 }
-                *reinterpret_cast<unsigned *>(sh_q + 4 * lane) =
-                    (unsigned)qv[0] | ((unsigned)qv[1] << 8) | ((unsigned)qv[2] << 16) | ((unsigned)qv[3] << 24);
-                if (lane == 0) { sh_i[0] = ovf; sh_i[1] = p; }
+                mx = wv::reduce<wv::OpMaxInt>(mx);
+                const bool bad = __ballot(bd) != 0ull;
+                if (lane == 0) { sh_i[0] = bad ? 1 : 0; sh_i[1] = mx; }
             }
             __syncthreads();
-            const int b_ovf = sh_i[0];
-            if (b_ovf != INT_MAX) {
-                // workgroup b_ovf's chain left the table from its (known) entry: everything before it is final -- keep
-                // those costs -- and the speculation rounds take over from there with that entry as the index
-                const A *hS = reinterpret_cast<const A *>(F.hyp_S);
-                A *S = reinterpret_cast<A *>(F.S);
-                for (int k = tid; k < 16 * b_ovf; k += NT) {
-                    const int b = k >> 4;
-                    S[k] = hS[((size_t)b * HYP_R + sh_q[b]) * 16 + (k & 15)];
-                }
-                nx.k_start = 16 * b_ovf;
-                nx.c = c_state + sh_q[b_ovf];
+            if (sh_i[0]) {
+                // a call that was not unimodal, an index beyond the candidates' reach or a look-back that timed out: the
+                // speculation rounds redo the iteration from its first sample
+                nx.k_start = 0;
+                nx.c = c_state;
                 nx.round = round + 1;
                 if (tid == 0) {
                     res->status = STATUS_NEED_ROUND;
-                    res->k_next = nx.k_start;
-                    res->c_next = nx.c;
+                    res->k_next = 0;
+                    res->c_next = c_state;
                     res->rounds = round + 1;
                     res->iter = iter;
                 }
@@ -1887,11 +1895,6 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
             }
             c_final = c_state + sh_i[1];
             hyp_done = true;
-            sel = sh_q;
-            if (tid < nb) F.hyp_q[tid] = sh_q[tid];  // (mppi_get_costs picks the samples' costs with it)
-            merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(F.hyp_heads), mr, sel);
-            merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(F.hyp_rec), T_pre, 0, mr, sel);
-            partials = F.hyp_rec;
         }
     }
     // --- sequential-waypoint speculation: did a sample move the index? ---------------------
@@ -1937,7 +1940,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     } else if (!XCHG) {
         if (count_hits) n_hit = A(0);
         merge_combine<A, NT, NWIN>(reinterpret_cast<const A *>(partials), F.n_part, T, (A)F.beta, mr, L.s, L.part, rho,
-                                   eta, eta2, store_w, sel, &n_hit);
+                                   eta, eta2, store_w, &n_hit);
         if (!count_hits) n_hit = A(0);
     } else {
         // this rank's record {rho, eta, eta2, W} from its block records, stored into every rank's buffer
@@ -2530,11 +2533,6 @@ void launch_exchange_probe(const FinalizeParams &F, int *ok_out, hipStream_t s) 
 }
 
 template <typename R>
-void launch_gather_costs(const R *hyp_S, const unsigned char *hyp_q, R *S, int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_costs<R>, dim3((K + 255) / 256), dim3(256), 0, s, hyp_S, hyp_q, S, K);
-}
-
-template <typename R>
 void launch_eval_index(const KParams<R> &P, const R *xy, int stride, int n, int p0, int sequential, int *idx_out, int *p_out,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_eval_index<R>, dim3(sequential ? 1 : (n + 63) / 64), dim3(64), 0, s, P.ref, P.n_ref, P.window, xy,
@@ -2581,7 +2579,7 @@ void launch_viz(const KParams<R> &P, const R *u_before, const R *u_upd, long lon
 
 #ifdef MPPI_STAMPS
 extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 128 ? n : 128));
 }
 #endif
 
@@ -2597,7 +2595,6 @@ extern "C" int mppi_debug_stamps(unsigned long long *out, int n) {
     template void launch_eval<R>(const KParams<R> &, int, const R *, const R *, const int *, int, R *, hipStream_t);   \
     template void launch_eval_filter<R>(const R *, R *, int, int, int, hipStream_t);                                 \
     template void launch_set_state_dev<R>(const KParams<R> &, const double *, int, hipStream_t);                     \
-    template void launch_gather_costs<R>(const R *, const unsigned char *, R *, int, hipStream_t);          \
     template void launch_viz<R>(const KParams<R> &, const R *, const R *, long long, float *, float *, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)

@@ -44,6 +44,11 @@ struct OpMinInt {
     template <typename R> static __device__ __forceinline__ int identity() { return 0x7fffffff; }
 };
 
+struct OpMaxInt {
+    static __device__ __forceinline__ int apply(int a, int b) { return b > a ? b : a; }
+    template <typename R> static __device__ __forceinline__ int identity() { return (int)0x80000000; }
+};
+
 // Inclusive scan over the 64 lanes (lane i <- op(x[0..i])).
 template <typename Op, typename R> __device__ __forceinline__ R scan_incl(R x) {
     const R id = Op::template identity<R>();
