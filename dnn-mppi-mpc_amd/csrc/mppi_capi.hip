@@ -265,8 +265,9 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
              c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && (c.search_window == HYP_WINDOW || c.search_window == HYP_WINDOW_CUDA) &&
              c.n_agents == 1 && h->n_part <= HYP_MAX_BLOCKS && !getenv("MPPI_NO_HYP");
     if (h->hyp) {
-        if ((e = hipMalloc((void **)&h->d_hyp_slots, sizeof(unsigned) * HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMalloc(look-back words)");
-        if ((e = hipMemset(h->d_hyp_slots, 0, sizeof(unsigned) * HYP_MAX_BLOCKS)) != hipSuccess) return fail(e, "hipMemset");
+        const size_t lb_bytes = sizeof(unsigned) * (size_t)LB_COPIES * LB_COPY_STRIDE;
+        if ((e = hipMalloc((void **)&h->d_hyp_slots, lb_bytes)) != hipSuccess) return fail(e, "hipMalloc(look-back words)");
+        if ((e = hipMemset(h->d_hyp_slots, 0, lb_bytes)) != hipSuccess) return fail(e, "hipMemset");
     }
     h->res_bytes = (h->res_bytes + 15) & ~(size_t)15;  // (the agents' results are stored back to back)
     if ((e = hipMalloc((void **)&h->d_st, B * sizeof(DevState))) != hipSuccess) return fail(e, "hipMalloc(state)");

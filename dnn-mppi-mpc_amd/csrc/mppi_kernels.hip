@@ -482,8 +482,10 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
     const int Mb = wv::read_lane(incl, 15);
     const bool bad_b = (__ballot((mv & LB_BAD) != 0) & 0xffffull) != 0ull;
     unsigned *slots = P.hyp_slots;
-    if (wid == 0 && lane == 0)
-        __hip_atomic_store(&slots[b], tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (LB_COPIES copies of the words, LB_COPY_STRIDE apart: 256 workgroups polling one kilobyte queue up at one memory
+    // channel -- workgroup b polls copy b mod LB_COPIES, every workgroup writes all of them, k_finalize reads copy 0)
+    if (wid == 0 && lane < LB_COPIES)
+        __hip_atomic_store(&slots[b + lane * LB_COPY_STRIDE], tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- this sample priced under every offset, lanes over the offset (wave 0: while its word travels) -----------
     {
         R cost_j = R(INFINITY);
@@ -519,7 +521,7 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
                 if (4 * lane < b) {
                     // (volatile: a load that bypasses this XCD's L2 -- the words come from the other XCDs' workgroups)
                     typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
-                    const lb_u4 w4 = *((const volatile __attribute__((address_space(1))) lb_u4 *)slots + lane);
+                    const lb_u4 w4 = *((const volatile __attribute__((address_space(1))) lb_u4 *)(slots + (b & (LB_COPIES - 1)) * LB_COPY_STRIDE) + lane);
                     const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -549,6 +551,7 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
         // the offsets this workgroup's calls were entered at stay within the candidates' reach (see LB_CAND)
         const int leave = max(E, Mb);
         const bool reach = leave < P.window && (leave + P.window <= LB_CAND || P.n_ref - c <= LB_CAND);
+        // (what a later workgroup reads of this word is the offset; the bad bit is k_finalize's: copy 0)
         if ((bad_e || !reach) && !bad_b && lane == 0) __hip_atomic_fetch_or(&slots[b], (unsigned)LB_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) sh_E = E;
         STAMP(13);
