@@ -258,10 +258,12 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     if ((e = hipMalloc(&h->d_heads2, 32 * n2)) != hipSuccess) return fail(e, "hipMalloc(heads2)");
     if ((e = hipMemset(h->d_heads, 0, 32 * n1)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(h->d_heads2, 0, 32 * n2)) != hipSuccess) return fail(e, "hipMemset");
-    // The sequential index in one launch: the fused one-sample-per-wave layout with one 64-step chunk, the reference's
-    // 20-candidate window, `S[k] =`, one agent, at most 256 workgroups (K <= 4096).  Anything else keeps the speculation
-    // rounds alone (they also serve as this path's fallback).  MPPI_NO_HYP=1 switches it off for A/B runs.
-    h->hyp = h->fused && (h->layout & LAYOUT_KIND) == LAYOUT_FUSED && c.T <= 64 && c.model == MPPI_MODEL_DIFFDRIVE &&
+    // The sequential index in one launch (look-back, LB_CAND in mppi_kernels.h): horizons of one 64-step pass in the
+    // one-sample-per-wave layout or the two-samples-per-wave layout with one pass per workgroup, the reference's 20- / 10-
+    // candidate windows, `S[k] =`, one agent, at most 512 workgroups (K <= 16384: configs 2 and 3).  Anything else keeps the
+    // speculation rounds alone (they also serve as this path's fallback).  MPPI_NO_HYP=1 switches it off for A/B runs.
+    const bool lb_layout = (h->layout & LAYOUT_KIND) == LAYOUT_FUSED || h->layout == LAYOUT_DUAL;  // (one pass per workgroup)
+    h->hyp = h->fused && lb_layout && c.T <= 64 && c.model == MPPI_MODEL_DIFFDRIVE &&
              c.waypoint_mode == MPPI_WAYPOINT_SEQUENTIAL && !c.accumulate_stage_cost && (c.search_window == HYP_WINDOW || c.search_window == HYP_WINDOW_CUDA) &&
              c.n_agents == 1 && h->n_part <= HYP_MAX_BLOCKS && !getenv("MPPI_NO_HYP");
     if (h->hyp) {

@@ -38,7 +38,7 @@ constexpr int HYP_WINDOW = 20, HYP_WINDOW_CUDA = 10;  // the search windows of t
 constexpr int LB_CAND = 32, LB_BAD = 0x80;
 constexpr unsigned LB_TAG_MASK = 0xffffff00u;
 constexpr unsigned long long LB_TIMEOUT_TICKS = 20000ull;  // 200 us at 100 MHz
-constexpr int HYP_MAX_BLOCKS = 256;  // workgroups whose words one finalize wave reads (four per lane)
+constexpr int HYP_MAX_BLOCKS = 512;  // workgroups whose words one wave reads (four per lane and 16-byte load)
 constexpr int LB_COPIES = 8, LB_COPY_STRIDE = 2048;  // copies of the words and the distance between them (in words: 8 KB)
 __host__ __device__ inline unsigned lb_tag(long long iter) { return ((unsigned)(iter + 1) & 0xffffffu) << 8; }
 

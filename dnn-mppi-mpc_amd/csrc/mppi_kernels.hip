@@ -394,6 +394,59 @@ template <int N> __device__ __forceinline__ void publish_first_mover(const int *
 // A call that is not unimodal, an index that leaves the candidates' reach or a wait that times out raises the slot's
 // `bad` bit: k_finalize hands the iteration to the speculation rounds.  Returns S_k; lane 0 stores S and pout.
 // ------------------------------------------------------------------------------------------
+// Look-back (one wave): waits until the words of workgroups [0, b) carry this iteration's tag; E = the largest offset among
+// them, bad = one of them is marked.  Four words per lane and 16-byte load, copy b mod LB_COPIES of the words; volatile =
+// loads that bypass this XCD's L2 (the words come from the other XCDs' workgroups).  Returns false when the wait timed out
+// (never seen: the iteration is then redone by the speculation rounds).
+__device__ __forceinline__ bool lb_wait(const unsigned *slots, int b, unsigned tag, int lane, int &E, bool &bad) {
+    static_assert(HYP_MAX_BLOCKS <= 512, "two 16-byte loads per lane cover the words");
+    typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
+    const volatile __attribute__((address_space(1))) lb_u4 *src =
+        (const volatile __attribute__((address_space(1))) lb_u4 *)(slots + (b & (LB_COPIES - 1)) * LB_COPY_STRIDE);
+    E = 0;
+    bad = false;
+    if (b <= 0) return true;
+    unsigned long long t0 = 0ull;
+    for (int n = 0;; ++n) {
+        bool ready = true, bd = false;
+        int mx = 0;
+#pragma unroll
+        for (int i = 0; i < HYP_MAX_BLOCKS / 256; ++i) {
+            const int first = 4 * (lane + 64 * i);
+            if (first < b) {
+                const lb_u4 w4 = src[lane + 64 * i];
+                const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (first + j < b) {
+                        ready &= (w[j] & LB_TAG_MASK) == tag;
+                        bd |= (w[j] & LB_BAD) != 0u;
+                        mx = max(mx, (int)(w[j] & (LB_BAD - 1)));
+                    }
+                }
+            }
+        }
+        if (__ballot(!ready) == 0ull) {
+            E = wv::reduce<wv::OpMaxInt>(mx);
+            bad = __ballot(bd) != 0ull;
+            return true;
+        }
+        if ((n & 15) == 15) {  // (the clock is a memory round trip of its own: looked at every 16th poll only)
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0ull) t0 = now;
+            if (now - t0 > LB_TIMEOUT_TICKS) return false;
+        }
+    }
+}
+// the word of workgroup b into every copy (lanes < LB_COPIES of one wave)
+__device__ __forceinline__ void lb_publish(unsigned *slots, int b, unsigned word, int lane) {
+    if (lane < LB_COPIES) __hip_atomic_store(&slots[b + lane * LB_COPY_STRIDE], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the offsets a workgroup's calls were entered at stay within the candidates' reach (see LB_CAND)
+__device__ __forceinline__ bool lb_reach(int leave, int window, int n_ref, int c) {
+    return leave < window && (leave + window <= LB_CAND || n_ref - c <= LB_CAND);
+}
+
 // pass A of one pair of candidates {x_2q, x_2q+1, y_2q, y_2q+1}: does this lane's distance fall at the first / the second
 // of them (f32: two packed subtractions, a packed product and a packed fma)
 typedef float lb_f2 __attribute__((ext_vector_type(2)));
@@ -410,6 +463,48 @@ __device__ __forceinline__ void lb_pair(const RefPair<double> &rp, double x, dou
     g0 = d0 < prev;
     g1 = d1 < d0;
     prev = d1;
+}
+
+// Pass A for the NP positions a lane owns (an idle one: x = NaN, it never descends): m[i] = this lane's count of descents
+// over the LB_CAND candidates of sh_c, `bad` = a call of this lane whose descents do not all come first.  Per candidate a
+// comparison and ONE add-with-carry per lane: the comparisons are shifted into a word, first candidate in the top bit
+// (w <- w + w + g), so that the count is a population count and "the descents come first" reads w == 1..10..0.  (Nothing
+// on the scalar unit: lane masks per candidate had the compiler spill SGPRs into VGPR lanes in the two-samples-per-wave
+// kernel, 330 lane moves per wave.)
+template <int NP, typename R>
+__device__ __forceinline__ void lb_scan(const RefPair<R> *sh_c, const R (&x)[NP], const R (&y)[NP], int (&m)[NP], bool &bad) {
+    static_assert(LB_CAND == 32, "one bit per candidate");
+    unsigned w[NP];
+    R prev[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        w[i] = 0u;
+        prev[i] = R(INFINITY);  // (candidate 0 is compared against +inf: the top bit, counted off below)
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < LB_CAND / 2; q0 += 4) {
+        RefPair<R> rp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rp[j] = sh_c[q0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                bool g0, g1;
+                lb_pair(rp[j], x[i], y[i], prev[i], g0, g1);
+                w[i] = w[i] + w[i] + (g0 ? 1u : 0u);
+                w[i] = w[i] + w[i] + (g1 ? 1u : 0u);
+            }
+        }
+    }
+    bad = false;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pc = __popc(w[i]);
+        m[i] = pc - 1;
+        // (an idle position: w = 0, nothing to check)
+        bad |= pc > 0 && w[i] != (0xffffffffu << (32 - pc));
+    }
 }
 
 // Returns, on lane l, S of the workgroup's sample l & 15 (every wave computes all sixteen); lane 0 stores S_k and pout.
@@ -444,32 +539,14 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
     int Mw = 0;
     bool bad_w = false;
     if (valid) {
-        // ---- pass A: this lane's call (the state after step `lane`) against the candidates, in pairs ------------
-        // Per candidate a comparison and a count per lane; that every lane's descents come first is checked on the lane
-        // masks (scalar unit): the sets of descending lanes must shrink from candidate to candidate.  An idle lane
-        // compares NaNs: it never descends.
-        const R x = sp.act ? sp.x : R(NAN), y = sp.y;
-        unsigned long long last = ~0ull, bad = 0ull;
-        int m = -1;  // (candidate 0 is compared against +inf: counted off here)
-        R prev = R(INFINITY);
-#pragma unroll
-        for (int q0 = 0; q0 < LB_CAND / 2; q0 += 4) {
-            RefPair<R> rp[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rp[i] = sh_c[q0 + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bool g0, g1;
-                lb_pair(rp[i], x, y, prev, g0, g1);
-                m += (g0 ? 1 : 0) + (g1 ? 1 : 0);
-                const unsigned long long b0 = __ballot(g0), b1 = __ballot(g1);
-                bad |= (b0 & ~last) | (b1 & ~b0);
-                last = b1;
-            }
-        }
-        if (!sp.act) m = 0;
-        Mw = wv::reduce<wv::OpMaxInt>(m);
-        bad_w = bad != 0ull;
+        // ---- pass A: this lane's call (the state after step `lane`) against the candidates (lb_scan) ---------------
+        const R xs[1] = {sp.act ? sp.x : R(NAN)}, ys[1] = {sp.y};
+        int m[1];
+        bool bad;
+        lb_scan<1, R>(sh_c, xs, ys, m, bad);
+        if (!sp.act) m[0] = 0;
+        Mw = wv::reduce<wv::OpMaxInt>(m[0]);
+        bad_w = __ballot(bad && sp.act) != 0ull;
     }
     STAMP(11);
     if (lane == 0) sh_M[wid] = Mw | (bad_w ? LB_BAD : 0);
@@ -484,8 +561,7 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
     unsigned *slots = P.hyp_slots;
     // (LB_COPIES copies of the words, LB_COPY_STRIDE apart: 256 workgroups polling one kilobyte queue up at one memory
     // channel -- workgroup b polls copy b mod LB_COPIES, every workgroup writes all of them, k_finalize reads copy 0)
-    if (wid == 0 && lane < LB_COPIES)
-        __hip_atomic_store(&slots[b + lane * LB_COPY_STRIDE], tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wid == 0) lb_publish(slots, b, tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, lane);
     // ---- this sample priced under every offset, lanes over the offset (wave 0: while its word travels) -----------
     {
         R cost_j = R(INFINITY);
@@ -509,48 +585,11 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
     }
     STAMP(14);
     if (wid == 0) {
-        // ---- look-back: the words of the workgroups before this one, four per lane and load ----------------------
+        // ---- look-back: the words of the workgroups before this one ----------------------------------------------
         int E = 0;
         bool bad_e = false;
-        if (b > 0) {
-            static_assert(HYP_MAX_BLOCKS <= 256, "one 16-byte load per lane covers the words");
-            unsigned long long t0 = 0ull;
-            for (int n = 0;; ++n) {
-                bool ready = true, bd = false;
-                int mx = 0;
-                if (4 * lane < b) {
-                    // (volatile: a load that bypasses this XCD's L2 -- the words come from the other XCDs' workgroups)
-                    typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
-                    const lb_u4 w4 = *((const volatile __attribute__((address_space(1))) lb_u4 *)(slots + (b & (LB_COPIES - 1)) * LB_COPY_STRIDE) + lane);
-                    const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (4 * lane + j < b) {
-                            ready &= (w[j] & LB_TAG_MASK) == tag;
-                            bd |= (w[j] & LB_BAD) != 0u;
-                            mx = max(mx, (int)(w[j] & (LB_BAD - 1)));
-                        }
-                    }
-                }
-                if (__ballot(!ready) == 0ull) {
-                    E = wv::reduce<wv::OpMaxInt>(mx);
-                    bad_e = __ballot(bd) != 0ull;
-                    break;
-                }
-                // (the clock is a memory round trip of its own: looked at every 16th poll only)
-                if ((n & 15) == 15) {
-                    const unsigned long long now = wall_clock64();
-                    if (t0 == 0ull) t0 = now;
-                    if (now - t0 > LB_TIMEOUT_TICKS) {  // (never seen; the iteration is redone by the speculation rounds)
-                        bad_e = true;
-                        break;
-                    }
-                }
-            }
-        }
-        // the offsets this workgroup's calls were entered at stay within the candidates' reach (see LB_CAND)
-        const int leave = max(E, Mb);
-        const bool reach = leave < P.window && (leave + P.window <= LB_CAND || P.n_ref - c <= LB_CAND);
+        if (!lb_wait(slots, b, tag, lane, E, bad_e)) bad_e = true;
+        const bool reach = lb_reach(max(E, Mb), P.window, P.n_ref, c);
         // (what a later workgroup reads of this word is the offset; the bad bit is k_finalize's: copy 0)
         if ((bad_e || !reach) && !bad_b && lane == 0) __hip_atomic_fetch_or(&slots[b], (unsigned)LB_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) sh_E = E;
@@ -781,7 +820,10 @@ constexpr int DUAL_WAVES = 16, DUAL_SAMPLES = 2 * DUAL_WAVES;
 // Batched agents (MULTI) bring thousands of workgroups per launch: the f32 diff-drive instantiation is held to 64 VGPRs (8
 // waves per SIMD) so that TWO workgroups share a CU and one's state wait, barrier and record stores run under the other's
 // arithmetic -- 32 agents of K = 4096: 1.0e11 -> 1.2e11 trajectory-steps/s.  (The race car would spill to scratch.)
-template <typename R, int MODEL, int SPW, bool MULTI, int SEQ, bool PLAIN>
+// LB: the instantiation that can resolve the sequential waypoint index in this launch (the look-back of fused_lookback for
+// two samples per wave and two steps per lane: KParams::hyp; one pass, one agent) -- picked by the host while the index
+// can still move, like k_rollout_fused's HYPK.
+template <typename R, int MODEL, int SPW, bool MULTI, int SEQ, bool PLAIN, bool LB = false>
 __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_DIFF && SPW == 2 && (MULTI || SEQ == 1)) ? 8 : 1) void k_rollout_dual(const DevState *st_pre, const KParams<R> P,
                                                                   R *__restrict__ partials) {
     const int agent = MULTI ? (int)blockIdx.y : 0;  // several agents per launch (see k_rollout_fused)
@@ -808,8 +850,19 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
     __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
     const ObsLanes<R> obs = load_obstacles(P, lane);
     const int wlen0 = window_len<R>(P.window, P.n_ref, c);
-    const bool seq_search = P.sequential && wlen0 > 1;  // (see k_rollout_fused)
-    const bool use_win = wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
+    // LB, the first round of an iteration whose waypoint index can move: resolved in this launch (see fused_lookback)
+    constexpr bool LBK = LB && MODEL == MODEL_DIFF && SPW == 2 && SEQ == 1 && !MULTI;
+    const bool lookback = LBK && P.hyp && sv.round == 0 && wlen0 > 1;
+    __shared__ RefPair<R> sh_c[LBK ? LB_CAND / 2 : 1];
+    __shared__ VecT4<R> sh_row[LBK ? LB_CAND : 1];
+    __shared__ R sh_cost[LBK ? ROWS : 1][LBK ? LB_CAND : 1];
+    __shared__ int sh_M[LBK ? ROWS : 1];
+    __shared__ int sh_E;
+    const int nc = min(LB_CAND, P.n_ref - c);
+    VecT4<R> lb_mine{R(1e30), R(1e30), R(0), R(0)};  // thread j < LB_CAND: candidate j's row (absent: far away), in flight during the draw
+    if (LBK && lookback && (int)threadIdx.x < nc) lb_mine = *reinterpret_cast<const VecT4<R> *>(ref + 4 * (c + (int)threadIdx.x));
+    const bool seq_search = !lookback && P.sequential && wlen0 > 1;  // (see k_rollout_fused)
+    const bool use_win = !lookback && wlen0 > 1 && wlen0 <= WINDOW_LDS_MAX;  // (a window of one candidate: nothing to stage or to search)
     __shared__ int sh_first;  // smallest sample of the workgroup that moved the index so far (see Rollout::chunk)
     if (use_win) stage_window(sh_win, ref, c, wlen0, (int)threadIdx.x, (int)blockDim.x);
     if (seq_search && threadIdx.x == 0) sh_first = NO_TRIGGER;
@@ -861,7 +914,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
     }
     STAMP(9);
     S_k = R(INFINITY);
-    if (__ballot(live) != 0ull) {  // at least one of the wave's two samples still needs its rollout
+    if (__ballot(live) != 0ull || lookback) {  // at least one of the wave's two samples still needs its rollout (look-back: every wave takes part)
         const bool exploit = (k + P.k_offset) < P.n_exploit;
         R u00 = 0, u01 = 0, u10 = 0, u11 = 0;  // u<step><channel>
         if (a0) { u00 = u_[2 * t0]; u01 = u_[2 * t0 + 1]; }
@@ -922,7 +975,86 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
         // ---- waypoint index of the lane's two calls ---------------------------------------------------------
         const int t_last = T - 1, lane_last = t_last >> 1, sub_last = t_last & 1;
         int idx0 = c, idx1 = c, p_half = c, idx_term = c;  // p_half / idx_term: uniform within a half
-        if (!P.sequential) {
+        R lb_total = R(INFINITY);
+        bool lb_done = false;
+        if constexpr (LBK) {
+          if (lookback) {
+            lb_done = true;
+            // ---- the sequential index in this launch: fused_lookback for a half-wave per sample, two calls per lane --------
+            static_assert(!LBK || (HL == LB_CAND && ROWS == 32), "a half-wave prices its sample under every offset, a lane per offset");
+            const unsigned tag = lb_tag(sv.iter);
+            const int b = blockIdx.x;
+            if (threadIdx.x < LB_CAND) {
+                const int j = threadIdx.x;
+                sh_row[j] = lb_mine;
+                R *pair = reinterpret_cast<R *>(&sh_c[j >> 1]);  // {x_2q, x_2q+1, y_2q, y_2q+1}
+                pair[j & 1] = lb_mine.x;
+                pair[2 + (j & 1)] = lb_mine.y;
+            }
+            __syncthreads();
+            // pass A: the lane's two calls
+            const R xs[2] = {(valid && a0) ? px0 : R(NAN), (valid && a1) ? px1 : R(NAN)}, ys[2] = {py0, py1};
+            int m2[2];
+            bool bad_l;
+            lb_scan<2, R>(sh_c, xs, ys, m2, bad_l);
+            const unsigned long long bad = __ballot(bad_l && valid);
+            STAMP(11);
+            int m = max((valid && a0) ? m2[0] : 0, (valid && a1) ? m2[1] : 0);
+            m = wv::scan_incl_half<wv::OpMaxInt>(m);
+            const int Mh = h ? wv::read_lane(m, 63) : wv::read_lane(m, 31);  // this half's (sample's) largest offset
+            const bool bad_h = ((h ? (bad >> 32) : bad) & 0xffffffffull) != 0ull;
+            if (l32 == 0) sh_M[sidx] = Mh | (bad_h ? LB_BAD : 0);
+            __syncthreads();
+            STAMP(12);
+            // the workgroup's maximum and, for sample s, the maximum of the samples before it (a half-wave of 32 values)
+            const int mv = sh_M[l32];
+            const int incl = wv::scan_incl_half<wv::OpMaxInt>(mv & (LB_BAD - 1));
+            const int Mb = wv::read_lane(incl, 31);
+            const bool bad_b = (__ballot((mv & LB_BAD) != 0) & 0xffffffffull) != 0ull;
+            unsigned *slots = P.hyp_slots;
+            if (wid == 0) lb_publish(slots, b, tag | (bad_b ? (unsigned)LB_BAD : 0u) | (unsigned)Mb, lane);
+            // this half's sample priced under every offset, lanes over the offset (`S[k] =`: the last step's stage cost
+            // and the terminal cost, both against the same waypoint)
+            {
+                const int src = (SPW == 2 ? 32 * h : 0) + lane_last;
+                const R lxs = sub_last ? px1 : px0, lys = sub_last ? py1 : py0, lyaws = sub_last ? yw1 : yw0;
+                const R xT = __shfl(lxs, src), yT = __shfl(lys, src), yawT = __shfl(lyaws, src);
+                const R ua = sub_last ? u10 : u00, ub = sub_last ? u11 : u01, va = sub_last ? v10 : v00, vb = sub_last ? v11 : v01;
+                const R ctrl = (ua * P.sinv[0] + ub * P.sinv[2]) * va + (ua * P.sinv[1] + ub * P.sinv[3]) * vb;  // :124
+                const R ctrlT = __shfl(ctrl, src);
+                const bool hit_lane = collided<false>(P, lxs, lys, lyaws, obs);
+                const bool hitT = ((__ballot(hit_lane) >> src) & 1ull) != 0ull;
+                const VecT4<R> row = sh_row[min(l32, nc - 1)];
+                const R rr[4] = {row.x, row.y, row.z, row.w};
+                R st_c = tracking_cost_row<R, MODEL>(P, P.ws, wrap_stage, rr, xT, yT, yawT, R(0));
+                if (hitT) st_c += P.penalty;
+                R term = tracking_cost_row<R, MODEL>(P, P.wt, wrap_term, rr, xT, yT, yawT, R(0));
+                if (hitT) term += P.penalty;
+                sh_cost[sidx][l32] = valid ? (st_c + P.gamma * ctrlT) + term : R(INFINITY);
+            }
+            STAMP(14);
+            if (wid == 0) {
+                int E = 0;
+                bool bad_e = false;
+                if (!lb_wait(slots, b, tag, lane, E, bad_e)) bad_e = true;
+                const bool reach = lb_reach(max(E, Mb), P.window, P.n_ref, c);
+                if ((bad_e || !reach) && !bad_b && lane == 0) __hip_atomic_fetch_or(&slots[b], (unsigned)LB_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) sh_E = E;
+                STAMP(13);
+            }
+            __syncthreads();
+            STAMP(15);
+            // pass B: lane l of a half holds sample l's index and cost; this half's own sample is sample sidx
+            const int shifted = wv::dpp<wv::DPP_WAVE_SHR1>(incl, 0);  // (every lane takes part: a lane switched off is no source)
+            const int before_l = l32 == 0 ? 0 : shifted;
+            const int a_l = min(max(max(sh_E, before_l), mv & (LB_BAD - 1)), nc - 1);
+            const R S_l = sh_cost[l32][a_l];
+            lb_total = __shfl(S_l, sidx);
+            p_half = c + __shfl(a_l, sidx);
+          }
+        }
+        if (lb_done) {
+        } else if (!P.sequential) {
             const int wlen = window_len<R>(P.window, P.n_ref, c);
             idx0 = use_win ? nearest_in_window_lds(sh_win, c, wlen, px0, py0) : nearest_in_window(ref, c, wlen, px0, py0);
             idx1 = use_win ? nearest_in_window_lds(sh_win, c, wlen, px1, py1) : nearest_in_window(ref, c, wlen, px1, py1);
@@ -999,7 +1131,9 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
         // state of the last step as held by lane_last of each half
         const R lx = sub_last ? px1 : px0, ly = sub_last ? py1 : py0, lyaw = sub_last ? yw1 : yw0, lvel = sub_last ? vl1 : vl0;
         R total;
-        if (P.accumulate) {
+        if (lb_done) {  // (priced above, under its exact index)
+            total = lb_total;
+        } else if (P.accumulate) {
             bool hit0, hit1;
             const R st0 = stage_cost(px0, py0, yw0, vl0, idx0, u00, u01, v00, v01, hit0, true);
             STAMP(12);
@@ -1035,7 +1169,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
             if (!lds_sum) S_[k] = total;
             pout_[k] = p_half;
         }
-        if (live && P.sequential && p_half != c) mover = min(mover, k);  // (uniform within the half; SEQ passes ascend)
+        if (live && P.sequential && !lb_done && p_half != c) mover = min(mover, k);  // (uniform within the half; SEQ passes ascend)
     }
     if (valid && !live) S_k = S_[k];  // final from an earlier speculation round
     if (SEQ == 2 && pass == 0) {
@@ -1804,9 +1938,14 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     unsigned long long peer_ptr = 0;
     if (XCHG) peer_ptr = load_peer_ptrs(F);
     MergeRegs<A, NT, NWIN> mr;
-    // (HYPK: wave 0 fetches the workgroups' look-back words as well, four per lane)
-    uint4 hwords = uint4{0, 0, 0, 0};
-    if (HYPK && wid == 0) hwords = reinterpret_cast<const uint4 *>(F.hyp_slots)[lane];
+    // (HYPK: wave 0 fetches the workgroups' look-back words as well, four per lane and load)
+    constexpr int HW = HYP_MAX_BLOCKS / 256;
+    uint4 hwords[HW];
+#pragma unroll
+    for (int i = 0; i < HW; ++i) {
+        hwords[i] = uint4{0, 0, 0, 0};
+        if (HYPK && wid == 0 && 4 * (lane + 64 * i) < F.hyp_blocks) hwords[i] = reinterpret_cast<const uint4 *>(F.hyp_slots)[lane + 64 * i];
+    }
     if (!ABI_RECS) {
         merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
         merge_load_tile<A, NT, NWIN>(reinterpret_cast<const A *>(partials_pre), T_pre, 0, mr);
@@ -1860,20 +1999,23 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     int c_final = c_state;
     bool hyp_done = false;
     if (HYPK) {  // (launched with the HYPK rollout kernel: the same condition there)
-        static_assert(!HYPK || (MODE == 0 && NWIN == 1 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
+        static_assert(!HYPK || (MODE == 0 && NWIN <= 2 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
         const bool hyp_round = round == 0 && min(F.window, F.n_ref - c_state) > 1;
         if (hyp_round) {
             int *sh_i = reinterpret_cast<int *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));  // {bad, largest offset}
             if (wid == 0) {
                 const unsigned tag = lb_tag(iter);
-                const unsigned hw[4] = {hwords.x, hwords.y, hwords.z, hwords.w};
                 int mx = 0;
                 bool bd = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (4 * lane + j < F.hyp_blocks) {
-                        bd |= (hw[j] & LB_TAG_MASK) != tag || (hw[j] & LB_BAD) != 0u;
-                        mx = max(mx, (int)(hw[j] & (LB_BAD - 1)));
+                for (int i = 0; i < HW; ++i) {
+                    const unsigned hw[4] = {hwords[i].x, hwords[i].y, hwords[i].z, hwords[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (4 * (lane + 64 * i) + j < F.hyp_blocks) {
+                            bd |= (hw[j] & LB_TAG_MASK) != tag || (hw[j] & LB_BAD) != 0u;
+                            mx = max(mx, (int)(hw[j] & (LB_BAD - 1)));
+                        }
                     }
                 }
                 mx = wv::reduce<wv::OpMaxInt>(mx);
@@ -2430,7 +2572,17 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
                            partials);                                                                                         \
     } while (0)
     case LAYOUT_DUAL:
-        if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(2, 2, !MULTI); else MPPI_LAUNCH_DUAL(2, 1, !MULTI); }
+        if (P.hyp && !MULTI && MODEL == MODEL_DIFF && !twice) {  // the sequential index resolved in the launch (LB)
+            if constexpr (!MULTI && MODEL == MODEL_DIFF) {
+                if (plain_ok) {
+                    MPPI_NOTE_KERNEL("k_rollout_dual<%s, 0, 2, false, 1, true, true>", type_name<R>());
+                    hipLaunchKernelGGL((k_rollout_dual<R, MODEL_DIFF, 2, false, 1, true, true>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+                } else {
+                    MPPI_NOTE_KERNEL("k_rollout_dual<%s, 0, 2, false, 1, false, true>", type_name<R>());
+                    hipLaunchKernelGGL((k_rollout_dual<R, MODEL_DIFF, 2, false, 1, false, true>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);
+                }
+            }
+        } else if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(2, 2, !MULTI); else MPPI_LAUNCH_DUAL(2, 1, !MULTI); }
         else if (MULTI && plain_ok && !twice) MPPI_LAUNCH_DUAL(2, 1, true);
         else { if (twice) MPPI_LAUNCH_DUAL(2, 2, false); else MPPI_LAUNCH_DUAL(2, 1, false); }
         break;
@@ -2517,8 +2669,11 @@ template <typename R> void launch_finalize(const FinalizeParams &F, bool abi_rec
     if (abi_recs) MPPI_FIN(1, 1, false);
     else if (F.x_nranks > 1) { if (two) MPPI_FIN(2, 2, false); else MPPI_FIN(2, 1, false); }
     else if (multi) { if (two) MPPI_FIN(0, 2, true); else MPPI_FIN(0, 1, true); }
-    else if (two) MPPI_FIN(0, 2, false);
-    else {
+    else if (two) {
+        if (F.hyp) hipLaunchKernelGGL((k_finalize<R, 0, 2, false, false, true>), grid, dim3(MERGE_THREADS), lds, s, F.partials, F.heads, st,
+                                      (const void *)F.u, F.T, F);
+        else MPPI_FIN(0, 2, false);
+    } else {
         const bool plain = F.sequential && F.plant && !F.use_args && !F.raise_at_path_end && !F.clamp_u && F.model == MODEL_DIFF &&
                            !F.u0_trace && F.filter_mode == FILTER_DIFF;
 #define MPPI_FIN_SINGLE(PLAIN_, HYPK_)                                                                                  \

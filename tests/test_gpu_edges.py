@@ -326,16 +326,18 @@ def test_exchange_api_errors():
     assert e.lib.mppi_comm_handle_bytes() == 64
 
 
+@pytest.mark.parametrize("dual", ["0", "1"])
 @pytest.mark.parametrize("variant", ["numpy", "cuda"])
 @pytest.mark.parametrize("precision", ["f64", "f32"])
-def test_one_launch_index_resolution_and_its_fallback(precision, variant):
-    """The sequential index resolved in one launch (per-call maps on 16 entry indices, fused_hyp) and its fallback: on a
-    densely sampled path a fast robot carries the index further than the table reaches within one iteration, so the
-    chain leaves it in some workgroup and the speculation rounds take over from there (rounds > 1); on a coarse path
-    the table suffices (rounds == 1).  Either way index, costs and controls equal the oracle's.  `variant="cuda"`: the
-    10-candidate window (and terminal yaw wrap) of mppi_differential_drive_cuda.py:201,:239 -- three blocks of
-    candidates in the sliding-window minimum instead of two."""
+def test_one_launch_index_resolution_and_its_fallback(monkeypatch, precision, variant, dual):
+    """The sequential index resolved in one launch (the threaded index as a running maximum of the calls' first minima,
+    a look-back across workgroups: fused_lookback / k_rollout_dual<..., LB>) and its fallback: on a densely sampled path a
+    fast robot carries the index further than the 32 candidates reach within one iteration, the workgroup that sees it
+    marks its word and the speculation rounds redo the iteration (rounds > 1); on a coarse path the candidates suffice
+    (rounds == 1).  Either way index, costs and controls equal the oracle's.  `variant="cuda"`: the 10-candidate window
+    (and terminal yaw wrap) of mppi_differential_drive_cuda.py:201,:239.  `dual`: one / two samples per wave."""
     import dnn_mppi_mpc_amd as pkg
+    monkeypatch.setenv("MPPI_DUAL", dual)
     seen = set()
     for n_ref, speed in ((400, 4.0), (60, 1.0)):
         rng = np.random.default_rng(n_ref)
@@ -357,6 +359,8 @@ def test_one_launch_index_resolution_and_its_fallback(precision, variant):
             u = c._calc_input_control(x0)[1]
             assert c.prev_way_point_idx == ref["idx_after"], (n_ref, it)
             seen.add(c.last_stats.rounds > 1)
+            if ref["idx_start"] < n_ref - 1:  # (the index can move: the instantiation that resolves it in the launch, HYPK / LB)
+                assert c._engine.rollout_kernel().endswith(", true>"), c._engine.rollout_kernel()
             tol = dict(rtol=1e-9, atol=1e-9) if precision == "f64" else dict(rtol=3e-4, atol=3e-4)
             np.testing.assert_allclose(c.sample_costs(), ref["S"], **tol)
             assert rmse(u, ref["u_returned"]) <= (1e-8 if precision == "f64" else 1e-4)

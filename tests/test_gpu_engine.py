@@ -1017,8 +1017,15 @@ def test_rollout_kernel_name_follows_the_layout():
     assert d._engine.rollout_kernel() == "k_rollout_stream<float, false, false, true>"  # frozen index, `S[k] =`: streamed
     d = pkg.MPPIAlgorithms(**dd_kwargs(16384, 50), precision="f32", seed=1)  # the sequential index: two samples per wave
     d._engine.set_state(np.zeros(3))
-    d._engine.run_closed_loop(1)
-    assert d._engine.rollout_kernel().startswith("k_rollout_dual<float, 0, 2, false, ")
+    c0 = d._engine.counters()
+    d._engine.run_closed_loop(6)
+    # (the index moving: the instantiation with the look-back, and ONE rollout launch per iteration)
+    assert d._engine.rollout_kernel() == "k_rollout_dual<float, 0, 2, false, 1, true, true>"
+    c1 = d._engine.counters()
+    assert c1["rollout_launches"] - c0["rollout_launches"] == 6 and c1["iterations"] - c0["iterations"] == 6
+    d._engine.run_closed_loop(60)
+    d._engine.run_closed_loop(2)
+    assert d._engine.rollout_kernel() == "k_rollout_dual<float, 0, 2, false, 1, true>"  # at the end of the path
 
 
 def test_learned_dynamics_outside_the_f16_range():

@@ -1,5 +1,5 @@
-"""Diagnostic: stamps of the traversal-phase kernels (the waypoint index moving) at BASELINE config 2, first and LAST
-workgroup of the rollout launch.  Uses lib/libmppi_hip_stamps.so (make stamps).  Not part of the product or the tests."""
+"""Diagnostic: stamps of the traversal-phase kernels (the waypoint index moving) at BASELINE config 2 (or `c3`), first and
+LAST workgroup of the rollout launch.  Uses lib/libmppi_hip_stamps.so (make stamps).  Not part of the product or the tests."""
 import ctypes as C
 import os
 import sys
@@ -14,9 +14,10 @@ import dnn_mppi_mpc_amd as pkg  # noqa: E402
 from dnn_mppi_mpc_amd import _capi  # noqa: E402
 
 _capi.LIB_PATH = os.environ.get("MPPI_STAMPS_LIB") or os.path.join(ROOT, "dnn-mppi-mpc_amd", "lib", "libmppi_hip_stamps.so")
-from bench import config2_kwargs  # noqa: E402
+from bench import config2_kwargs, config3_kwargs  # noqa: E402
 
-ctrl = pkg.MPPIAlgorithms(**config2_kwargs(), precision="f32", seed=1)
+C3 = len(sys.argv) > 1 and sys.argv[1] == "c3"  # config 3: two samples per wave (k_rollout_dual<..., LB>)
+ctrl = pkg.MPPIAlgorithms(**(config3_kwargs() if C3 else config2_kwargs()), precision="f32", seed=1)
 eng = ctrl._engine
 lib = eng.lib
 names = {0: "roll:start", 1: "roll:state loaded", 9: "roll:eps ready", 10: "roll:dynamics done", 11: "roll:pass A done",
