@@ -2567,7 +2567,7 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
     switch (P.layout & LAYOUT_KIND) {
 #define MPPI_LAUNCH_DUAL(SPW_, SEQ_, PLAIN_)                                                                                  \
     do {                                                                                                                      \
-        MPPI_NOTE_KERNEL("k_rollout_dual<%s, %d, %d, %s, %d, %s>", type_name<R>(), MODEL, SPW_, tf(MULTI), SEQ_, tf(PLAIN_)); \
+        MPPI_NOTE_KERNEL("k_rollout_dual<%s, %d, %d, %s, %d, %s, false>", type_name<R>(), MODEL, SPW_, tf(MULTI), SEQ_, tf(PLAIN_)); \
         hipLaunchKernelGGL((k_rollout_dual<R, MODEL, SPW_, MULTI, SEQ_, PLAIN_>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, \
                            partials);                                                                                         \
     } while (0)

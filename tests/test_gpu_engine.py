@@ -1025,7 +1025,7 @@ def test_rollout_kernel_name_follows_the_layout():
     assert c1["rollout_launches"] - c0["rollout_launches"] == 6 and c1["iterations"] - c0["iterations"] == 6
     d._engine.run_closed_loop(60)
     d._engine.run_closed_loop(2)
-    assert d._engine.rollout_kernel() == "k_rollout_dual<float, 0, 2, false, 1, true>"  # at the end of the path
+    assert d._engine.rollout_kernel() == "k_rollout_dual<float, 0, 2, false, 1, true, false>"  # at the end of the path
 
 
 def test_learned_dynamics_outside_the_f16_range():

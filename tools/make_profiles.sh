@@ -22,6 +22,7 @@ CMD[c5]="bench.py --workload c5 --steps 12 --warmup 2 $Q"
 CMD[eps_c2]="bench.py --eps hbm --workload c2 --steps 200 --warmup 20"
 CMD[eps_c4]="bench.py --eps hbm --workload c4 --steps 100 --warmup 10"
 CMD[trav]="tools/traverse_only.py 60"
+CMD[trav_c3]="tools/traverse_only.py 60 c3"
 reduce() {  # <pass name>: the pass's counter CSV -> <pass name>.reduced.csv; the raw output (large) is dropped
   local d="$OUT/$1"
   local f
@@ -30,13 +31,13 @@ reduce() {  # <pass name>: the pass's counter CSV -> <pass name>.reduced.csv; th
   find "$d" -mindepth 1 -delete; rmdir "$d"
 }
 echo "== kernel traces"; date
-for W in c2 c3 c4 c5 eps_c2 eps_c4 trav; do
+for W in c2 c3 c4 c5 eps_c2 eps_c4 trav trav_c3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$W" -- python3 ${CMD[$W]} > "$OUT/kt_$W.log" 2>&1 || echo "kt $W failed"
   f=$(find "$OUT/kt_$W" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$W.csv"
   find "$OUT/kt_$W" -mindepth 1 -delete; rmdir "$OUT/kt_$W"
 done
 echo "== PMC: instruction counts"; date
-for W in c2 c3 c4 eps_c2 eps_c4 trav; do
+for W in c2 c3 c4 eps_c2 eps_c4 trav trav_c3; do
   timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_inst_$W" -- python3 ${CMD[$W]} > "$OUT/pmc_inst_$W.log" 2>&1 || echo "pmc_inst $W failed"
   reduce "pmc_inst_$W"
 done
