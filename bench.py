@@ -602,18 +602,21 @@ def main():
             dt = float(t.item())
         idx_timed = int(eng.stats.idx_after)
 
-        def phase(n_skip, n):  # wall time per iteration of iterations [n_skip, n_skip + n) of an episode
-            restart()
-            if n_skip:
-                run(n_skip)
-            barrier()
-            t1 = time.perf_counter()
-            run(n)
-            barrier()
-            return (time.perf_counter() - t1) / n
+        def phase(n_skip, n, reps=1):  # wall time per iteration of iterations [n_skip, n_skip + n) of an episode
+            ts = []                      # (one call of n iterations, its fixed cost included; median of `reps` episodes)
+            for _ in range(reps):
+                restart()
+                if n_skip:
+                    run(n_skip)
+                barrier()
+                t1 = time.perf_counter()
+                run(n)
+                barrier()
+                ts.append((time.perf_counter() - t1) / n)
+            return float(np.median(ts))
         phases = None
         if traverse:
-            phases = {"traverse": phase(0, traverse), "hold": phase(episode // 2, episode // 2)}
+            phases = {"traverse": phase(0, traverse, 9), "hold": phase(episode // 2, episode // 2)}
 
         # Kernel duration, live, with HIP events on the launch stream -- over WHOLE EPISODES of fixed length, whatever
         # --steps is, and over the same episodes (same noise counter) both times:
@@ -847,7 +850,7 @@ def main():
                                        "collective": "one all-gather per iteration (torch.distributed, RCCL)"}[ctrl.exchange]},
                "iter_latency_us": 1e6 * dt / args.steps,
                "phase_latency_us": None if phases is None else
-                                   {"traverse (first %d iterations of an episode)" % traverse: 1e6 * phases["traverse"],
+                                   {"traverse (first %d iterations of an episode, one call, median of 9 episodes)" % traverse: 1e6 * phases["traverse"],
                                     "hold (second half of an episode)": 1e6 * phases["hold"]},
                "host_in_loop_latency_us": None if lat is None else 1e6 * lat,
                "roofline": roof}

@@ -2023,6 +2023,13 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
                 if (lane == 0) { sh_i[0] = bad ? 1 : 0; sh_i[1] = mx; }
             }
             __syncthreads();
+            // The words are spent: cleared (every copy), so that no later launch can take them for its own -- a caller may
+            // set the iteration counter back (mppi_set_iteration), and a tag alone would then repeat.
+            {
+                const int nb4 = (F.hyp_blocks + 3) >> 2;
+                uint4 *w4 = reinterpret_cast<uint4 *>(const_cast<unsigned *>(F.hyp_slots));
+                for (int i = tid; i < LB_COPIES * nb4; i += NT) w4[(i / nb4) * (LB_COPY_STRIDE / 4) + (i % nb4)] = uint4{0u, 0u, 0u, 0u};
+            }
             if (sh_i[0]) {
                 // a call that was not unimodal, an index beyond the candidates' reach or a look-back that timed out: the
                 // speculation rounds redo the iteration from its first sample

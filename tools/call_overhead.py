@@ -9,7 +9,7 @@ from bench import config2_kwargs
 ctrl = pkg.MPPIAlgorithms(**config2_kwargs(), precision="f32", seed=1)
 eng = ctrl._engine
 eng.set_state(np.zeros(3)); eng.run_closed_loop(300); torch.cuda.synchronize()
-for n in (1, 2, 5, 10, 20, 50, 200):
+for n in (1, 2, 5, 10, 20, 50, 200, 1000, 3000):
     ts = []
     for rep in range(30):
         torch.cuda.synchronize()
