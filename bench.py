@@ -733,9 +733,9 @@ def main():
         pmc, pmc_src = stamped_profile("pmc", build_id)
         ran = kms["ran"]  # the instantiation the timed launches took, as rocprofv3 spells it
         layout = eng.counters()["rollout_layout"]
-        # workgroups of one rollout launch: 16 waves with a sample each, or two (the dual layout: low bits == 1), or two in
-        # sequence on top (+4); the learned-dynamics kernel: 64 samples per workgroup
-        per_wg = 64 if c5 else 16 * (2 if (layout & 3) == 1 else 1) * (2 if layout & 4 else 1)
+        # workgroups of one rollout launch: 16 waves with a sample each, or two (the dual layout: low bits == 1, three steps
+        # per lane: == 3), or two in sequence on top (+4); the learned-dynamics kernel: 64 samples per workgroup
+        per_wg = 64 if c5 else 16 * (2 if (layout & 3) in (1, 3) else 1) * (2 if layout & 4 else 1)
         wgs_launch = (K_local + per_wg - 1) // per_wg
         pk = pmc_kernel(pmc, ran, wgs_launch) if ran else None
         pk_why = pmc_src if pk is not None else (pmc_src if pmc is None else
@@ -746,7 +746,8 @@ def main():
             traffic = (2.0 * pk["counters"]["FETCH_SIZE"] + pk["counters"]["WRITE_SIZE"]) * 1024.0
         kernel_name = ("k_rollout_mlp_h3 (operands split into two f16 numbers, three v_mfma_f32_32x32x16_f16 per product)" if c5 else
                        "k_rollout_dual<float, diffdrive + circles, 2 samples per wave / 2 steps per lane>" if c3 else
-                       "k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>" if c4 else
+                       ("k_rollout_tri<float, racecar, 2 samples per wave / 3 steps per lane>" if (layout & 3) == 3 else
+                        "k_rollout_dual<float, racecar, 1 sample per wave / 2 steps per lane>") if c4 else
                        "k_rollout_fused<float, diffdrive, 1 chunk, single agent, PLAIN>")
         sequential = not (sharded or c4 or c5)
         phase = ("hold phase only (graph replays need a waypoint index at rest; the eager marginal figure beside it is "

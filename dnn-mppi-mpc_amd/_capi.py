@@ -23,7 +23,7 @@ FILTER_DIFFDRIVE, FILTER_RACECAR, FILTER_NONE, FILTER_TORCH = 0, 1, 2, 3
 OBSTACLE_NONE, OBSTACLE_CIRCLE, OBSTACLE_OUTLINE = 0, 1, 2
 OK, ERR_BAD_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_PATH_END, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 ERR_COMM = -8
-LAYOUT_FUSED, LAYOUT_DUAL, LAYOUT_PAIR, LAYOUT_KIND, LAYOUT_TWICE = 0, 1, 2, 3, 4  # mppi_get_rollout_layout
+LAYOUT_FUSED, LAYOUT_DUAL, LAYOUT_PAIR, LAYOUT_TRI, LAYOUT_KIND, LAYOUT_TWICE = 0, 1, 2, 3, 3, 4  # mppi_get_rollout_layout (KIND: mask)
 
 
 class MppiConfig(C.Structure):

@@ -225,8 +225,11 @@ extern "C" int mppi_create(const mppi_config *cfg, mppi_handle **out) {
     h->n_blocks = reduce_blocks(c.K, tpb);
     h->fused = fused_supported(c.T) && !getenv("MPPI_FORCE_UNFUSED");
     h->graph_on = getenv("MPPI_GRAPH") && atoi(getenv("MPPI_GRAPH")) != 0;  // (opt-in: see ensure_graph)
+    // (k_rollout_tri: the race car as the reference runs it -- frozen index, `S[k] +=` -- one agent, f32)
+    const bool tri_ok = c.model == MPPI_MODEL_RACECAR && !h->f64 && c.n_agents == 1 && c.waypoint_mode == MPPI_WAYPOINT_FROZEN &&
+                        c.accumulate_stage_cost;
     h->layout = rollout_layout(c.K, c.T, c.n_agents, c.model == MPPI_MODEL_RACECAR ? MODEL_RACE : MODEL_DIFF, h->f64,
-                               c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT);
+                               c.waypoint_mode == MPPI_WAYPOINT_PER_ROLLOUT, tri_ok);
     h->n_part = h->fused ? fused_blocks(c.K, c.T, h->layout) : h->n_blocks;
     if (c.model == MPPI_MODEL_DIFFDRIVE_MLP) h->n_part = mlp_blocks(c.K, 64);  // (mppi_set_mlp sets it again for the kernel that serves the model)
     h->res_bytes = sizeof(StepResult) + sizeof(double) * 2 * c.T;

@@ -199,8 +199,10 @@ bool fused_supported(int T);
 const char *last_rollout_kernel();
 // Which fused rollout kernel serves (K, T): decided ONCE per handle (it reads the MPPI_DUAL / MPPI_PAIR / MPPI_SEQ
 // overrides) and carried in KParams::layout, so that a launch costs no environment lookups.
-enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };
-int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout = false);  // n_agents: problems batched in one launch
+enum { LAYOUT_FUSED = 0, LAYOUT_DUAL = 1, LAYOUT_PAIR = 2, LAYOUT_TRI = 3, LAYOUT_KIND = 3, LAYOUT_TWICE = 4 };  // (KIND: mask)
+// n_agents: problems batched in one launch; tri_ok: the handle is what k_rollout_tri serves (race car, f32, frozen index,
+// `S[k] +=`, one agent) -- it takes horizons of 65 .. 96 steps then
+int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout = false, bool tri_ok = false);
 int fused_blocks(int K, int T, int layout);  // workgroups = block records of one launch
 // records launch_rollout_fused(P) leaves (the streaming kernel, which serves tensors of noise, leaves fewer: see k_rollout_stream)
 template <typename R> int fused_records(const KParams<R> &P);

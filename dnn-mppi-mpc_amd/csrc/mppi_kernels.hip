@@ -1264,6 +1264,215 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
 }
 
 // ------------------------------------------------------------------------------------------
+// 64 < T <= 96, race car, f32: two samples per wave and THREE steps per lane.  With two steps per lane and one sample per
+// wave (k_rollout_dual<.., 1, ..>) a horizon of 75 steps keeps 38 of 64 lanes busy; here a half-wave owns a sample and lane l
+// of the half the steps 3l, 3l+1, 3l+2 -- 25 of 32 lanes at T = 75.  A lane's three steps straddle two Philox blocks (the
+// sampler's counter is (k, t >> 1): words r0,r1 for even t, r2,r3 for odd t), so it draws two blocks and uses six of
+// their eight words.  Same arithmetic per step as k_rollout_dual (the association of the prefix sums differs); frozen
+// waypoint index, `S[k] +=` summed in the reference's order through LDS (a lane per sample), one record per 32 samples.
+// ------------------------------------------------------------------------------------------
+constexpr int TRI_STEPS = 3, TRI_SAMPLES = 2 * DUAL_WAVES;
+// SHARE: held to 64 VGPRs so that two workgroups share a CU (one's barriers, one-wave sum and record stores run under the
+// other's arithmetic): K = 65536 59 -> 46 us per launch.  A launch of at most one workgroup per CU takes the instantiation
+// without the cap (two registers more, 6 % faster at K = 8192).
+template <bool PLAIN, bool SHARE>
+__global__ __launch_bounds__(64 * DUAL_WAVES, SHARE ? 8 : 1) void k_rollout_tri(const DevState *st_pre, const KParams<float> P,
+                                                                                float *__restrict__ partials) {
+    using R = float;
+    constexpr int NS = TRI_STEPS, HL = 32, ROWS = TRI_SAMPLES;
+    const bool use_philox = PLAIN || P.use_philox, clamp_rollout = PLAIN || P.clamp_rollout;
+    const bool wrap_stage = PLAIN || P.wrap_stage, wrap_term = PLAIN || P.wrap_term;  // (PLAIN: the race car's own switches)
+    __shared__ R sh_S[ROWS];
+    __shared__ R sh_e[ROWS];
+    __shared__ __attribute__((aligned(16))) R sh_acc[ROWS][2 * NS * HL];
+    __shared__ float sh_st[ROWS][129];  // per-step costs + the terminal cost of each sample; pitch 129: a column is conflict-free
+    __shared__ RefPair<R> sh_win[WINDOW_LDS_MAX / 2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+    const int sidx = wid * 2 + h;
+    const DevState sv = load_state(P, st_pre);
+    const int c = sv.c, T = P.T;
+    const unsigned iter = (unsigned)sv.iter;
+    const R *__restrict__ ref = P.ref;
+    int t[NS];
+    bool a[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        t[i] = NS * l32 + i;
+        a[i] = t[i] < T;
+    }
+    const ObsLanes<R> obs = load_obstacles(P, lane);
+    const int wlen = window_len<R>(P.window, P.n_ref, c);
+    const bool use_win = wlen > 1 && wlen <= WINDOW_LDS_MAX;
+    if (use_win) {
+        stage_window(sh_win, ref, c, wlen, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
+    const int k = (blockIdx.x * DUAL_WAVES + wid) * 2 + h;  // this half-wave's sample
+    const bool valid = k < P.K;
+
+    // ---- S1: the lane's noise for its three steps ------------------------------------------------------------
+    float e[NS][2];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { e[i][0] = 0.f; e[i][1] = 0.f; }
+    if (valid && a[0]) {
+        if (use_philox) {
+            const unsigned jA = (unsigned)(NS * l32) >> 1;  // the block of step 3l; the lane's last step sits in block jA + 1
+            unsigned rA[4], rB[4];
+            px::philox4x32_10((unsigned)(k + P.k_offset), jA, iter, (unsigned)P.noise_stream, P.seed_lo, P.seed_hi, rA);
+            px::philox4x32_10((unsigned)(k + P.k_offset), jA + 1u, iter, (unsigned)P.noise_stream, P.seed_lo, P.seed_hi, rB);
+            const bool odd = (l32 & 1) != 0;  // 3l odd: the lane's steps take words {A2,A3}, {B0,B1}, {B2,B3}; else {A0,A1}, {A2,A3}, {B0,B1}
+            px::box_muller(odd ? rA[2] : rA[0], odd ? rA[3] : rA[1], P.chol, e[0][0], e[0][1]);
+            px::box_muller(odd ? rB[0] : rA[2], odd ? rB[1] : rA[3], P.chol, e[1][0], e[1][1]);
+            px::box_muller(odd ? rB[2] : rB[0], odd ? rB[3] : rB[1], P.chol, e[2][0], e[2][1]);
+        } else {
+            const float *pe = eps_tensor(P, iter, 0) + ((size_t)k * T + t[0]) * 2;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                if (a[i]) {
+                    const float2 ev = *reinterpret_cast<const float2 *>(pe + 2 * i);
+                    e[i][0] = ev.x;
+                    e[i][1] = ev.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (!a[i]) { e[i][0] = 0.f; e[i][1] = 0.f; }
+    }
+
+    // ---- S2: controls (:116-121), S3: dynamics as scans over the lane totals of each half -----------------
+    const bool exploit = (k + P.k_offset) < P.n_exploit;
+    R u[NS][2], v[NS][2];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        u[i][0] = a[i] ? P.u[2 * t[i]] : R(0);
+        u[i][1] = a[i] ? P.u[2 * t[i] + 1] : R(0);
+        v[i][0] = exploit ? u[i][0] + e[i][0] : e[i][0];
+        v[i][1] = exploit ? u[i][1] + e[i][1] : e[i][1];
+        if (clamp_rollout) {
+            v[i][0] = mf::clamp(v[i][0], P.umax0);
+            v[i][1] = mf::clamp(v[i][1], P.umax1);
+        }
+        if (!a[i]) { v[i][0] = 0; v[i][1] = 0; }
+    }
+    auto before = [&](R lane_total, R start) {  // `start` + the totals of the lanes before this one in its half
+        return start + wv::shift_up1_half(wv::scan_incl_half<wv::OpAdd>(lane_total), R(0));
+    };
+    // mppi_race_car.py:190-193, controls = [steer, accel]
+    R vb[NS], vl[NS], yb[NS], yw[NS], px_[NS], py_[NS], sn[NS], cs[NS];
+    {
+        R d[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) d[i] = a[i] ? v[i][1] * P.dt : R(0);
+        R run = before((d[0] + d[1]) + d[2], (R)sv.x0[3]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { vb[i] = run; run += d[i]; vl[i] = run; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) d[i] = a[i] ? vb[i] / P.wheel_base * mf::tan_(v[i][0]) * P.dt : R(0);
+        run = before((d[0] + d[1]) + d[2], (R)sv.x0[2]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { yb[i] = run; run += d[i]; yw[i] = run; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) mf::sincos_(yb[i], sn[i], cs[i]);
+        R dx[NS], dy[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            dx[i] = a[i] ? vb[i] * cs[i] * P.dt : R(0);
+            dy[i] = a[i] ? vb[i] * sn[i] * P.dt : R(0);
+        }
+        run = before((dx[0] + dx[1]) + dx[2], (R)sv.x0[0]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { run += dx[i]; px_[i] = run; }
+        run = before((dy[0] + dy[1]) + dy[2], (R)sv.x0[1]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { run += dy[i]; py_[i] = run; }
+    }
+
+    // ---- the frozen waypoint index of the lane's three calls (mppi_race_car.py:157-174) and the costs ---------
+    float *row = sh_st[sidx];
+    int idx[NS];
+    bool hit[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        idx[i] = use_win ? nearest_in_window_lds(sh_win, c, wlen, px_[i], py_[i]) : nearest_in_window(ref, c, wlen, px_[i], py_[i]);
+        // (the sine / cosine of the yaw after step i are those the dynamics of step i + 1 took)
+        hit[i] = i + 1 < NS ? collided<true>(P, px_[i], py_[i], yw[i], obs, true, sn[i + 1 < NS ? i + 1 : 0], cs[i + 1 < NS ? i + 1 : 0])
+                            : collided<true>(P, px_[i], py_[i], yw[i], obs);
+        R st_c = tracking_cost<R, MODEL_RACE>(P, P.ws, wrap_stage, idx[i], px_[i], py_[i], yw[i], vl[i]);
+        if (hit[i]) st_c += P.penalty;
+        const R ctrl = u[i][0] * (P.sinv[0] * v[i][0] + P.sinv[1] * v[i][1]) + u[i][1] * (P.sinv[2] * v[i][0] + P.sinv[3] * v[i][1]);  // mppi_race_car.py:84
+        if (valid && a[i]) row[t[i]] = st_c + P.gamma * ctrl;
+    }
+    {
+        const int t_last = T - 1, lane_last = t_last / NS, sub_last = t_last - NS * lane_last;
+        if (valid && l32 == lane_last) {  // the terminal cost: the state after the last step (:97-99)
+            const R lx = sub_last == 0 ? px_[0] : sub_last == 1 ? px_[1] : px_[2], ly = sub_last == 0 ? py_[0] : sub_last == 1 ? py_[1] : py_[2];
+            const R lyaw = sub_last == 0 ? yw[0] : sub_last == 1 ? yw[1] : yw[2], lvel = sub_last == 0 ? vl[0] : sub_last == 1 ? vl[1] : vl[2];
+            const int li = sub_last == 0 ? idx[0] : sub_last == 1 ? idx[1] : idx[2];
+            const bool lh = sub_last == 0 ? hit[0] : sub_last == 1 ? hit[1] : hit[2];
+            R term = tracking_cost<R, MODEL_RACE>(P, P.wt, wrap_term, li, lx, ly, lyaw, lvel);
+            if (lh) term += P.penalty;
+            row[T] = term;
+        }
+    }
+    __syncthreads();
+    // `S[k] += ...` in the reference's order, a lane per sample (see k_rollout_dual)
+    if (wid == 0 && lane < ROWS) {
+        const int k_s = blockIdx.x * ROWS + lane;
+        float S = INFINITY;
+        if (k_s < P.K) {
+            const float *rw = sh_st[lane];
+            S = 0.f;
+            for (int tt = 0; tt <= T; ++tt) S += rw[tt];
+            P.S[k_s] = S;
+            P.pout[k_s] = c;
+        }
+        sh_S[lane] = S;
+    }
+    __syncthreads();
+
+    // ---- the workgroup's softmin record over its 32 samples (S5-S6) -------------------------------------------
+    const R S_k = sh_S[sidx];
+    const R sv_l = sh_S[l32];
+    const unsigned long long hb = __ballot(sv_l >= P.penalty && sv_l < R(INFINITY));
+    const int n_hit_i = __popcll(hb & 0xffffffffull);
+    const R rho = wv::read_lane(wv::scan_incl_half<wv::OpMin>(sv_l), HL - 1);
+    const R ew = valid ? mf::exp_(-P.beta * (S_k - rho)) : R(0);  // mppi_race_car.py:197-209
+    if (l32 == 0) sh_e[sidx] = ew;
+    {
+        R *dst = &sh_acc[sidx][2 * NS * l32];  // columns 2 t + channel of the lane's steps: contiguous
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            dst[2 * i] = ew * e[i][0];
+            dst[2 * i + 1] = ew * e[i][1];
+        }
+    }
+    __syncthreads();
+    const size_t slot = blockIdx.x;
+    R *out = partials + slot * record_len(T, (int)sizeof(R));
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {  // W_b[t] = sum_k e_k eps[k, t]
+        R acc = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) acc += sh_acc[q][i];
+        out[4 + i] = acc;
+    }
+    if (threadIdx.x == 64 * (DUAL_WAVES - 1)) {
+        R eta = 0, eta2 = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const R w = sh_e[q];
+            eta += w;
+            eta2 += w * w;
+        }
+        out[0] = rho;
+        out[1] = eta;
+        out[2] = eta2;
+        *reinterpret_cast<VecT4<R> *>(P.heads + 4 * slot) =
+            VecT4<R>{rho, eta, eta2, P.obstacle_model != OBS_NONE ? (R)n_hit_i : R(0)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The memory-bound form of the analytic path (north star: "coalesced HBM loads of the [K,T,nu] noise tensor"): the noise
 // of `_calc_epsilon` (mppi_differential_drive.py:273-283) arrives as a tensor in HBM -- the caller's, or a slot of the
 // noise ring (mppi_set_noise_ring) -- instead of being drawn in registers.  Read by the general kernels above, one
@@ -2505,7 +2714,14 @@ static bool pair_layout(int T) {
     if (const char *e = getenv("MPPI_PAIR")) return atoi(e) != 0;
     return true;
 }
-int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout) {
+// 64 < T <= 96, race car: two samples per wave, three steps per lane (k_rollout_tri).  MPPI_TRI=0 keeps the pair layout (A/B).
+static bool tri_layout(int T, bool tri_ok) {
+    if (!tri_ok || T <= 64 || T > 32 * TRI_STEPS) return false;
+    if (const char *e = getenv("MPPI_TRI")) return atoi(e) != 0;
+    return true;
+}
+int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rollout, bool tri_ok) {
+    if (!per_rollout && model == MODEL_RACE && !f64 && n_agents <= 1 && tri_layout(T, tri_ok)) return LAYOUT_TRI;
     // (per-rollout index threading lives in the one-sample-per-wave kernels: Rollout::chunk)
     const int kind = per_rollout ? LAYOUT_FUSED : dual_layout(K, T, n_agents) ? LAYOUT_DUAL : pair_layout(T) ? LAYOUT_PAIR : LAYOUT_FUSED;
     if (kind == LAYOUT_FUSED) return kind;
@@ -2523,7 +2739,8 @@ int rollout_layout(int K, int T, int n_agents, int model, bool f64, bool per_rol
 }
 int fused_blocks(int K, int T, int layout) {
     // (the pair layout: DUAL_WAVES = 16 = FUSED_WAVES samples per pass)
-    const int per_block = ((layout & LAYOUT_KIND) == LAYOUT_DUAL ? DUAL_SAMPLES : FUSED_WAVES) * (layout & LAYOUT_TWICE ? 2 : 1);
+    const int kind = layout & LAYOUT_KIND;
+    const int per_block = ((kind == LAYOUT_DUAL || kind == LAYOUT_TRI) ? DUAL_SAMPLES : FUSED_WAVES) * (layout & LAYOUT_TWICE ? 2 : 1);
     return (K + per_block - 1) / per_block;
 }
 
@@ -2592,6 +2809,19 @@ template <typename R, int MODEL, bool MULTI> static void launch_fused_mm(const K
         } else if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(2, 2, !MULTI); else MPPI_LAUNCH_DUAL(2, 1, !MULTI); }
         else if (MULTI && plain_ok && !twice) MPPI_LAUNCH_DUAL(2, 1, true);
         else { if (twice) MPPI_LAUNCH_DUAL(2, 2, false); else MPPI_LAUNCH_DUAL(2, 1, false); }
+        break;
+    case LAYOUT_TRI:
+        if constexpr (sizeof(R) == 4 && MODEL == MODEL_RACE && !MULTI) {
+#define MPPI_LAUNCH_TRI(PLAIN_, SHARE_)                                                                                   \
+    do {                                                                                                                  \
+        MPPI_NOTE_KERNEL("k_rollout_tri<%s, %s>", tf(PLAIN_), tf(SHARE_));                                                \
+        hipLaunchKernelGGL((k_rollout_tri<PLAIN_, SHARE_>), grid, dim3(64 * DUAL_WAVES), 0, s, P.st, P, partials);        \
+    } while (0)
+            const bool share = grid.x > 256;  // (more than one workgroup per CU)
+            if (plain_ok) { if (share) MPPI_LAUNCH_TRI(true, true); else MPPI_LAUNCH_TRI(true, false); }
+            else { if (share) MPPI_LAUNCH_TRI(false, true); else MPPI_LAUNCH_TRI(false, false); }
+#undef MPPI_LAUNCH_TRI
+        }
         break;
     case LAYOUT_PAIR:
         if (plain_dual) { if (twice) MPPI_LAUNCH_DUAL(1, 2, !MULTI); else MPPI_LAUNCH_DUAL(1, 1, !MULTI); }

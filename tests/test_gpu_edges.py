@@ -56,10 +56,12 @@ def test_ragged_diffdrive_shapes_match_oracle(monkeypatch, dual, K, T, n_ref, ob
 
 
 @pytest.mark.parametrize("dual", ["0", "1"])
-@pytest.mark.parametrize("K,T", [(1, 5), (19, 5), (64, 64), (65, 63), (130, 30)])
+@pytest.mark.parametrize("K,T", [(1, 5), (19, 5), (64, 64), (65, 63), (130, 30), (33, 65), (40, 75), (3, 94), (65, 96), (20, 97)])
 def test_ragged_racecar_shapes_match_oracle(monkeypatch, dual, K, T):
+    """(64 < T <= 96: `dual` switches between three steps per lane, k_rollout_tri, and two, k_rollout_dual<.., 1, ..>.)"""
     import dnn_mppi_mpc_amd as pkg
     monkeypatch.setenv("MPPI_DUAL", dual)
+    monkeypatch.setenv("MPPI_TRI", dual)
     lem = mppi_oracle.generate_lemniscate_racecar(60, 10.0)
     kw = dict(ref_path=lem, horizon_step_T=T, number_of_samples_K=K, param_exploration=0.2, param_alpha=0.8,
               param_lambda=30.0, visualize_optimal_traj=True, visualze_sampled_trajs=False)
@@ -73,6 +75,8 @@ def test_ragged_racecar_shapes_match_oracle(monkeypatch, dual, K, T):
     np.testing.assert_allclose(c.sample_costs(), ref["S"], rtol=3e-5, atol=1e-3)
     assert rmse(u, ref["u_returned"]) <= 1e-4
     assert c.prev_waypoints_idx == ref["idx_after"]
+    if 64 < T <= 96:
+        assert c._engine.rollout_kernel().startswith("k_rollout_tri<" if dual == "1" else "k_rollout_dual<float, 1, 1, ")
 
 
 def test_boundary_errors():
