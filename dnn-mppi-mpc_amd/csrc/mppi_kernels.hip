@@ -998,14 +998,14 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
             bool bad_l;
             lb_scan<2, R>(sh_c, xs, ys, m2, bad_l);
             const unsigned long long bad = __ballot(bad_l && valid);
-            STAMP(11);
+            STAMP(27);
             int m = max((valid && a0) ? m2[0] : 0, (valid && a1) ? m2[1] : 0);
             m = wv::scan_incl_half<wv::OpMaxInt>(m);
             const int Mh = h ? wv::read_lane(m, 63) : wv::read_lane(m, 31);  // this half's (sample's) largest offset
             const bool bad_h = ((h ? (bad >> 32) : bad) & 0xffffffffull) != 0ull;
             if (l32 == 0) sh_M[sidx] = Mh | (bad_h ? LB_BAD : 0);
             __syncthreads();
-            STAMP(12);
+            STAMP(28);
             // the workgroup's maximum and, for sample s, the maximum of the samples before it (a half-wave of 32 values)
             const int mv = sh_M[l32];
             const int incl = wv::scan_incl_half<wv::OpMaxInt>(mv & (LB_BAD - 1));
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
                 if (hitT) term += P.penalty;
                 sh_cost[sidx][l32] = valid ? (st_c + P.gamma * ctrlT) + term : R(INFINITY);
             }
-            STAMP(14);
+            STAMP(30);
             if (wid == 0) {
                 int E = 0;
                 bool bad_e = false;
@@ -1040,10 +1040,10 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
                 const bool reach = lb_reach(max(E, Mb), P.window, P.n_ref, c);
                 if ((bad_e || !reach) && !bad_b && lane == 0) __hip_atomic_fetch_or(&slots[b], (unsigned)LB_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) sh_E = E;
-                STAMP(13);
+                STAMP(29);
             }
             __syncthreads();
-            STAMP(15);
+            STAMP(31);
             // pass B: lane l of a half holds sample l's index and cost; this half's own sample is sample sidx
             const int shifted = wv::dpp<wv::DPP_WAVE_SHR1>(incl, 0);  // (every lane takes part: a lane switched off is no source)
             const int before_l = l32 == 0 ? 0 : shifted;

@@ -371,7 +371,8 @@ int mppi_time_rollout_launch(mppi_handle *h, int32_t n_slots, int32_t extra, voi
 
 /* Which fused rollout kernel serves the handle (fixed at mppi_create from K x n_agents and T; diagnostic, for tests and
  * profiles): low two bits 0 = one sample per wave, lanes over the horizon; 1 = two samples per wave, two steps per lane
- * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128);
+ * (T <= 64 and >= 8192 samples per launch); 2 = one sample per wave, two steps per lane (64 < T <= 128); 3 = two samples per
+ * wave, three steps per lane (the race car as the reference runs it, f32, 64 < T <= 96);
  * +4 = every (half-)wave rolls out two samples in sequence.  -1: the handle does not use the fused kernels. */
 int mppi_get_rollout_layout(const mppi_handle *h, int32_t *layout);
 /* The kernel instantiation the handle's last rollout-class launch took, spelled as rocprofv3 prints it (e.g.

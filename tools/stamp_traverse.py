@@ -24,6 +24,10 @@ names = {0: "roll:start", 1: "roll:state loaded", 9: "roll:eps ready", 10: "roll
          12: "roll:barrier 1", 13: "roll:look-back done (wave 0)", 14: "roll:costs by offset", 15: "roll:barrier 2",
          2: "roll:S done", 3: "roll:block sync", 4: "roll:end"}
 order = (0, 1, 9, 10, 11, 12, 13, 14, 15, 2, 3, 4)
+if C3:  # (k_rollout_dual's own stamps 11 .. 14 sit in its cost section: the look-back path has 27 .. 31)
+    names.update({27: "roll:pass A done", 28: "roll:barrier 1", 29: "roll:look-back done (wave 0)", 30: "roll:costs by offset",
+                  31: "roll:barrier 2"})
+    order = (0, 1, 9, 10, 27, 28, 29, 30, 31, 2, 3, 4)
 acc = {}
 for ep in range(6):
     ctrl.restart_episode(np.zeros(3))
