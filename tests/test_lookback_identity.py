@@ -91,3 +91,27 @@ def test_conditions_hold_throughout_config_2s_traversal():
         moved += int(pred[-1] != c)
         x = mo.diffdrive_plant_step(x, out["u0_returned"], kw["delta_t"])
     assert moved >= 10  # (the index is carried along the path iteration after iteration)
+
+
+def test_a_path_that_folds_back_inside_the_candidates_is_detected():
+    """A hairpin: the way back runs 0.15 m beside the way out, so a call beside both branches sees its distances fall, rise and
+    fall again within the 32 candidates -- `predict` (as pass A in the kernels) must flag the iteration, and wherever it does
+    not, the running maximum must still equal the scan."""
+    out = np.stack([np.linspace(0.0, 1.2, 13), np.zeros(13)], 1)
+    back = np.stack([np.linspace(1.2, 0.0, 13), np.full(13, 0.15)], 1)
+    ref_xy = np.concatenate([out, back[1:], np.stack([np.linspace(-0.1, -3.0, 30), np.full(30, 0.15)], 1)])
+    rng = np.random.default_rng(5)
+    flagged = agreed = 0
+    for c in (0, 3, 6, 10, 14, 20):
+        K, T = 32, 20
+        pos = np.stack([rng.uniform(0.2, 1.1, (K, T)), rng.uniform(-0.05, 0.2, (K, T))], -1)
+        px = np.concatenate([pos[:, :, 0], pos[:, -1:, 0]], 1).reshape(-1)
+        py = np.concatenate([pos[:, :, 1], pos[:, -1:, 1]], 1).reshape(-1)
+        truth, _ = mo.sequential_waypoint_scan(px, py, ref_xy, c, W)
+        pred, ok = predict(px, py, ref_xy, c)
+        if ok:
+            np.testing.assert_array_equal(pred, truth)
+            agreed += 1
+        else:
+            flagged += 1
+    assert flagged >= 3, (flagged, agreed)
