@@ -42,7 +42,8 @@ struct mppi_handle {
     unsigned short *d_mlp16 = nullptr;  // the same as f16 hi / lo planes (k_rollout_mlp_h3)
     // one-launch resolution of the sequential waypoint index (LB_CAND in mppi_kernels.h)
     bool hyp = false;
-    unsigned *d_hyp_slots = nullptr;  // one look-back word per workgroup
+    unsigned *d_hyp_slots = nullptr;  // one look-back word per workgroup (LB_COPIES copies)
+    unsigned lb_seq = 0;              // tag of the last rollout / finalize launch pair that used them
     std::vector<double> ref_host;   // [n_ref][4] as the kernels see it (rounded to the handle's precision)
     StepResult *res_mapped = nullptr;  // device-side address of the pinned host result (polled completion)
     long long seq = 0;
@@ -625,7 +626,7 @@ template <typename R> static KParams<R> make_params(const mppi_handle *h, const 
     // the kernels that can resolve the sequential index in one launch -- while that index can still move: once it sits
     // on the last waypoint (it only grows) every search window holds one candidate and the lean kernels serve
     P.hyp = h->hyp && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
-    P.pad_hyp = 0;
+    P.lb_seq = 0;
     P.hyp_slots = h->d_hyp_slots;
     return P;
 }
@@ -673,6 +674,8 @@ static FinalizeParams make_finalize(const mppi_handle *h, const void *partials, 
     F.hyp = h->hyp && partials == h->d_partials && !(h->idx_valid && h->n_ref > 0 && h->idx >= h->n_ref - 1);
     F.hyp_blocks = h->n_part;
     F.hyp_slots = h->d_hyp_slots;
+    F.lb_seq = 0;
+    F.pad_lb = 0;
     return F;
 }
 
@@ -759,7 +762,14 @@ template <typename R>
 static void launch_slot(mppi_handle *h, const KParams<R> &P, FinalizeParams F, hipStream_t s) {
     const bool tm = timing_on(h);
     arm_exchange(h, F);
-    launch_front<R>(h, P, F.beta, s, &F.partials, &F.heads, &F.n_part, tm);
+    if (P.hyp) {  // the look-back words of this launch pair carry its own tag (lb_tag)
+        if ((++h->lb_seq & 0xffffffu) == 0u) ++h->lb_seq;
+        KParams<R> Pl = P;
+        Pl.lb_seq = F.lb_seq = h->lb_seq;
+        launch_front<R>(h, Pl, F.beta, s, &F.partials, &F.heads, &F.n_part, tm);
+    } else {
+        launch_front<R>(h, P, F.beta, s, &F.partials, &F.heads, &F.n_part, tm);
+    }
     launch_back<R>(h, F, false, s, tm);
 }
 

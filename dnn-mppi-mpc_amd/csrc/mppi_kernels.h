@@ -33,14 +33,16 @@ __host__ __device__ inline size_t xchg_slot_bytes(int T, int nranks) {
 // index p keeps [p, p+W) inside them (p <= LB_CAND - W, or the path ends inside them) and below W; a call that is not
 // unimodal, an index beyond that reach or a look-back that times out sets the `bad` bit of the workgroup's word, and
 // k_finalize hands the iteration to the speculation rounds (exact either way).
-// Word of workgroup b: [31:8] iteration tag, [7] bad, [6:0] largest offset of the workgroup's own calls.
+// Word of workgroup b: [31:8] the launch pair's tag, [7] bad, [6:0] largest offset of the workgroup's own calls.
 constexpr int HYP_WINDOW = 20, HYP_WINDOW_CUDA = 10;  // the search windows of the reference's files
 constexpr int LB_CAND = 32, LB_BAD = 0x80;
 constexpr unsigned LB_TAG_MASK = 0xffffff00u;
 constexpr unsigned long long LB_TIMEOUT_TICKS = 20000ull;  // 200 us at 100 MHz
 constexpr int HYP_MAX_BLOCKS = 512;  // workgroups whose words one wave reads (four per lane and 16-byte load)
 constexpr int LB_COPIES = 8, LB_COPY_STRIDE = 2048;  // copies of the words and the distance between them (in words: 8 KB)
-__host__ __device__ inline unsigned lb_tag(long long iter) { return ((unsigned)(iter + 1) & 0xffffffu) << 8; }
+// (the tag: a sequence number the host draws per rollout / finalize launch pair -- KParams::lb_seq, never 0 mod 2^24 --, so
+// that no word of an earlier launch can be taken for this one's, whatever the caller does to the iteration counter)
+__host__ __device__ inline unsigned lb_tag(unsigned seq) { return (seq & 0xffffffu) << 8; }
 
 // Controller state that lives on the device (so closed loops need no host round trip).
 struct DevState {
@@ -122,8 +124,8 @@ template <typename R> struct KParams {
     // all samples' calls) and starts from the x0 call's index at every sample: samples stay independent
     int per_rollout, pad_pr;
     // one-launch resolution of the sequential index (see LB_CAND)
-    int hyp;                // the handle qualifies (fused layout, T <= 64, window 20 / 10, `S[k] =`, one agent, <= 256 workgroups)
-    int pad_hyp;
+    int hyp;                // the handle qualifies (one pass per workgroup, T <= 64, window 20 / 10, `S[k] =`, one agent, <= 512 workgroups)
+    unsigned lb_seq;        // this launch pair's tag (see lb_tag)
     unsigned *hyp_slots;    // [HYP_MAX_BLOCKS] one word per workgroup
 };
 
@@ -161,6 +163,7 @@ struct FinalizeParams {
     // one-launch resolution of the sequential index (see LB_CAND / KParams)
     int hyp, hyp_blocks;
     const unsigned *hyp_slots;
+    unsigned lb_seq, pad_lb;
 };
 
 // learned residual dynamics (mppi_mlp.hip): device pointers to fragment-packed weights

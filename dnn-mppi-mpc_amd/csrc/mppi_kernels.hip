@@ -519,7 +519,7 @@ __device__ __forceinline__ R fused_lookback(const KParams<R> &P, const DevState 
     const bool valid = __builtin_amdgcn_readfirstlane((int)valid_in) != 0;  // (wave-uniform: said so that the counting below stays scalar)
     const int c = sv.c, b = blockIdx.x;
     const int nc = min(LB_CAND, P.n_ref - c);  // (> 1: the caller's condition)
-    const unsigned tag = lb_tag(sv.iter);
+    const unsigned tag = lb_tag(P.lb_seq);
     // thread j < LB_CAND fetches candidate j's row (an absent one: far away, it never descends); the loads are in flight
     // during the draw
     VecT4<R> mine{R(1e30), R(1e30), R(0), R(0)};
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
             lb_done = true;
             // ---- the sequential index in this launch: fused_lookback for a half-wave per sample, two calls per lane --------
             static_assert(!LBK || (HL == LB_CAND && ROWS == 32), "a half-wave prices its sample under every offset, a lane per offset");
-            const unsigned tag = lb_tag(sv.iter);
+            const unsigned tag = lb_tag(P.lb_seq);
             const int b = blockIdx.x;
             if (threadIdx.x < LB_CAND) {
                 const int j = threadIdx.x;
@@ -2147,13 +2147,14 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
     unsigned long long peer_ptr = 0;
     if (XCHG) peer_ptr = load_peer_ptrs(F);
     MergeRegs<A, NT, NWIN> mr;
-    // (HYPK: wave 0 fetches the workgroups' look-back words as well, four per lane and load)
+    // (HYPK: every wave fetches the workgroups' look-back words as well, four per lane and load -- each wave reduces them
+    // itself, which saves an exchange through LDS and a barrier)
     constexpr int HW = HYP_MAX_BLOCKS / 256;
     uint4 hwords[HW];
 #pragma unroll
     for (int i = 0; i < HW; ++i) {
         hwords[i] = uint4{0, 0, 0, 0};
-        if (HYPK && wid == 0 && 4 * (lane + 64 * i) < F.hyp_blocks) hwords[i] = reinterpret_cast<const uint4 *>(F.hyp_slots)[lane + 64 * i];
+        if (HYPK && 4 * (lane + 64 * i) < F.hyp_blocks) hwords[i] = reinterpret_cast<const uint4 *>(F.hyp_slots)[lane + 64 * i];
     }
     if (!ABI_RECS) {
         merge_load_heads<A, NT, NWIN>(reinterpret_cast<const A *>(heads_pre), mr);
@@ -2211,35 +2212,23 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
         static_assert(!HYPK || (MODE == 0 && NWIN <= 2 && NT == MERGE_THREADS), "the resolution is part of the plain 256-thread finalize");
         const bool hyp_round = round == 0 && min(F.window, F.n_ref - c_state) > 1;
         if (hyp_round) {
-            int *sh_i = reinterpret_cast<int *>(smem + sizeof(A) * merge_lds_elems(T, W, sizeof(A), NT));  // {bad, largest offset}
-            if (wid == 0) {
-                const unsigned tag = lb_tag(iter);
-                int mx = 0;
-                bool bd = false;
+            const unsigned tag = lb_tag(F.lb_seq);
+            int mx = 0;
+            bool bd = false;
 #pragma unroll
-                for (int i = 0; i < HW; ++i) {
-                    const unsigned hw[4] = {hwords[i].x, hwords[i].y, hwords[i].z, hwords[i].w};
+            for (int i = 0; i < HW; ++i) {
+                const unsigned hw[4] = {hwords[i].x, hwords[i].y, hwords[i].z, hwords[i].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (4 * (lane + 64 * i) + j < F.hyp_blocks) {
-                            bd |= (hw[j] & LB_TAG_MASK) != tag || (hw[j] & LB_BAD) != 0u;
-                            mx = max(mx, (int)(hw[j] & (LB_BAD - 1)));
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * (lane + 64 * i) + j < F.hyp_blocks) {
+                        bd |= (hw[j] & LB_TAG_MASK) != tag || (hw[j] & LB_BAD) != 0u;
+                        mx = max(mx, (int)(hw[j] & (LB_BAD - 1)));
                     }
                 }
-                mx = wv::reduce<wv::OpMaxInt>(mx);
-                const bool bad = __ballot(bd) != 0ull;
-                if (lane == 0) { sh_i[0] = bad ? 1 : 0; sh_i[1] = mx; }
             }
-            __syncthreads();
-            // The words are spent: cleared (every copy), so that no later launch can take them for its own -- a caller may
-            // set the iteration counter back (mppi_set_iteration), and a tag alone would then repeat.
-            {
-                const int nb4 = (F.hyp_blocks + 3) >> 2;
-                uint4 *w4 = reinterpret_cast<uint4 *>(const_cast<unsigned *>(F.hyp_slots));
-                for (int i = tid; i < LB_COPIES * nb4; i += NT) w4[(i / nb4) * (LB_COPY_STRIDE / 4) + (i % nb4)] = uint4{0u, 0u, 0u, 0u};
-            }
-            if (sh_i[0]) {
+            const int lb_max = wv::reduce<wv::OpMaxInt>(mx);
+            const bool lb_bad = __ballot(bd) != 0ull;
+            if (lb_bad) {
                 // a call that was not unimodal, an index beyond the candidates' reach or a look-back that timed out: the
                 // speculation rounds redo the iteration from its first sample
                 nx.k_start = 0;
@@ -2254,7 +2243,7 @@ __device__ __forceinline__ void finalize_body(const void *partials_pre, const vo
                 }
                 return leave();
             }
-            c_final = c_state + sh_i[1];
+            c_final = c_state + lb_max;
             hyp_done = true;
         }
     }
