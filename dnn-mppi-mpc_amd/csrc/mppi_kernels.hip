@@ -666,7 +666,7 @@ __device__ __forceinline__ void per_rollout_thread(const KParams<R> &P, int c, c
 // MULTI: several agents per launch, one row of workgroups (blockIdx.y) each; a single agent compiles to the
 // offset-free code (the offsets cost config 2 half a microsecond per iteration when they were unconditional)
 // SPEC: 0 general, 1 no obstacles, 2 no obstacles + the PLAIN switches (see Rollout)
-// HYPK: the instantiation that can resolve the sequential index in one launch (fused_hyp).  A separate instantiation,
+// HYPK: the instantiation that can resolve the sequential index in one launch (fused_lookback).  A separate instantiation,
 // picked by the host while the waypoint index can still move (KParams::hyp): carrying that code costs the lean kernel
 // 0.17 us per launch in registers and LDS (A/B on one box), and at the end of the path nothing moves any more.
 template <typename R, int MODEL, int NCH, bool MULTI, int SPEC, bool HYPK = false>
