@@ -844,32 +844,23 @@ static int host_x0_call(const mppi_handle *h, const double *x0) {
 
 // wait for the result of the launches just enqueued: poll the completion word the finalize kernel writes into
 // mapped host memory (saves the device-to-host copy launch and the stream synchronisation), or copy + synchronise
-static int wait_result(mppi_handle *h, long long seq, hipStream_t s, double expect_s = 0.0, double t_enqueue = 0.0) {
+static int wait_result(mppi_handle *h, long long seq, hipStream_t s) {
     if (seq) {
         volatile long long *flag = &h->h_res->seq;
-        // The poll saves a copy launch and a stream synchronisation (~7 us) on SHORT calls.  A long batch (thousands of
-        // iterations, or config 5's milliseconds per iteration) should not spin a host core for its whole duration, and
-        // handing the wait to hipStreamSynchronize costs ~0.4 ms of wake-up at the end (200 iterations per call: 11.0 us per
-        // iteration against 9.2 at 50).  So: `expect_s` = what the launches enqueued since `t_enqueue` should take by the
-        // last call's pace; the host sleeps through the first 80 % of it (in slices of at most 1 ms), spins from there,
-        // and hands a wait that overruns its estimate fourfold (+ 50 ms) to the runtime, which also surfaces a failed launch.
-        const double t0 = t_enqueue > 0.0 ? t_enqueue : now_s();
-        const double give_up = 4.0 * expect_s + 0.05;
+        // The poll saves a copy launch and a stream synchronisation (~7 us) on short calls, and on long ones the wake-up of
+        // hipStreamSynchronize (up to 0.4 ms per call on some boxes: 200 iterations per call 11.0 us per iteration against
+        // 9.2 at 50).  So the host spins for up to 20 ms -- two episodes of the reference driver's run at config 2 -- and only
+        // then hands the wait to the runtime (config 5's tens of milliseconds per call; it also surfaces a failed launch).
+        // (Sleeping through an ESTIMATE of the call's duration was tried: the pace of the previous call is the wrong
+        // estimate across a phase change, and an overslept call costs more than the spin saves.)
+        const double t0 = now_s();
         for (long long spins = 0; *flag != seq; ++spins) {
             __builtin_ia32_pause();
-            if ((spins & 1023) != 1023) continue;
-            const double el = now_s() - t0;
-            if (el > give_up) {
+            if ((spins & 1023) == 1023 && now_s() - t0 > 0.020) {
                 HIPCHECK(h, hipStreamSynchronize(s));
                 HIPCHECK(h, hipGetLastError());
                 if (*flag != seq) FAIL(h, MPPI_ERR_HIP, "the finalize kernel never published its result");
                 break;
-            }
-            const double left = 0.8 * expect_s - el;
-            if (left > 2.0e-4) {
-                const double nap = std::min(left, 1.0e-3);
-                timespec ts{0, (long)(1e9 * nap)};
-                nanosleep(&ts, nullptr);
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1600,8 +1591,7 @@ static int closed_loop_impl(mppi_handle *h, int n_iters, double *u0_trace, mppi_
         HIPCHECK(h, hipGetLastError());
         h->t_enqueue_s += now_s() - t_enq;
         if (poll) {
-            // (the pace of the last call; the first call of a handle has none and spins)
-            if (int rc = wait_result(h, h->seq, s, 1e-6 * h->last_iter_us * (double)todo, t_enq)) return rc;
+            if (int rc = wait_result(h, h->seq, s)) return rc;
         } else {
             HIPCHECK(h, hipMemcpyAsync(h->h_res, h->d_res, (size_t)h->B * h->res_bytes, hipMemcpyDeviceToHost, s));
             HIPCHECK(h, hipStreamSynchronize(s));
