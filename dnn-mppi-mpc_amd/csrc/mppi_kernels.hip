@@ -1022,8 +1022,18 @@ __global__ __launch_bounds__(64 * DUAL_WAVES, (sizeof(R) == 4 && MODEL == MODEL_
                 const R ua = sub_last ? u10 : u00, ub = sub_last ? u11 : u01, va = sub_last ? v10 : v00, vb = sub_last ? v11 : v01;
                 const R ctrl = (ua * P.sinv[0] + ub * P.sinv[2]) * va + (ua * P.sinv[1] + ub * P.sinv[3]) * vb;  // :124
                 const R ctrlT = __shfl(ctrl, src);
-                const bool hit_lane = collided<false>(P, lxs, lys, lyaws, obs);
-                const bool hitT = ((__ballot(hit_lane) >> src) & 1ull) != 0ull;
+                // the collision test of that one state (:301-313): a lane per circle -- lanes m < 32 of the wave hold circles
+                // 0 .. 31 -- instead of every lane walking all circles for a result only one lane's state needs
+                bool hitT;
+                if (P.obstacle_model == OBS_CIRCLE && P.n_obs <= 32) {
+                    const R ox = __shfl(obs.x, l32), oy = __shfl(obs.y, l32), o2 = __shfl(obs.r2, l32);
+                    const R ddx = xT - ox, ddy = yT - oy;
+                    const unsigned long long hm = __ballot(l32 < P.n_obs && ddx * ddx + ddy * ddy < o2);
+                    hitT = ((h ? (hm >> 32) : hm) & 0xffffffffull) != 0ull;
+                } else {
+                    const bool hit_lane = collided<false>(P, lxs, lys, lyaws, obs);
+                    hitT = ((__ballot(hit_lane) >> src) & 1ull) != 0ull;
+                }
                 const VecT4<R> row = sh_row[min(l32, nc - 1)];
                 const R rr[4] = {row.x, row.y, row.z, row.w};
                 R st_c = tracking_cost_row<R, MODEL>(P, P.ws, wrap_stage, rr, xT, yT, yawT, R(0));
