@@ -378,7 +378,7 @@ int mppi_get_rollout_layout(const mppi_handle *h, int32_t *layout);
 /* The kernel instantiation the handle's last rollout-class launch took, spelled as rocprofv3 prints it (e.g.
  * "k_rollout_fused<float, 0, 1, false, 2, false>", "k_rollout_dual<float, 1, 1, false, 2, true>"): bench.py looks the
  * launch's counter figures up under this name in profiles/.  A learned-dynamics handle answers as soon as mppi_set_mlp has
- * run: "k_rollout_mlp_h3<false>" (operands as two f16 halves, the default) or "k_rollout_mlp(" (f32-input MFMA: chosen by
+ * run: "k_rollout_mlp_h3<false, 8, 2, 3>" (operands as two f16 halves, the default) or "k_rollout_mlp(" (f32-input MFMA: chosen by
  * MPPI_MLP_F32=1, or by mppi_set_mlp itself when a weight exceeds the f16 range). */
 int mppi_get_rollout_kernel(const mppi_handle *h, char *buf, int32_t n);
 

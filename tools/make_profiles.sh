@@ -61,6 +61,7 @@ timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$O
 timeout -k 10 300 python3 bench.py --workload c3 --steps 1000 --warmup 100 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err" || echo "bench c3 failed"
 timeout -k 10 300 python3 bench.py --workload c4 --steps 300 --warmup 30 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err" || echo "bench c4 failed"
 timeout -k 10 300 python3 bench.py --workload c5 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || echo "bench c5 failed"
+MPPI_MLP_TERMS=2 timeout -k 10 300 python3 bench.py --workload c5 --no-cpu-baseline > "$OUT/bench_c5_two_terms.json" 2> "$OUT/bench_c5_two_terms.err" || echo "bench c5 (two terms) failed"
 timeout -k 10 300 python3 bench.py --eps hbm --workload c2 > "$OUT/bench_eps_c2.json" 2> "$OUT/bench_eps_c2.err" || echo "bench eps c2 failed"
 timeout -k 10 300 python3 bench.py --eps hbm --workload c4 > "$OUT/bench_eps_c4.json" 2> "$OUT/bench_eps_c4.err" || echo "bench eps c4 failed"
 echo "== self-launched 2-rank rehearsals (one GPU, gloo host side)"; date
@@ -68,6 +69,6 @@ for W in c2 c4; do
   MPPI_BENCH_DEVICE=0 MPPI_BENCH_BACKEND=gloo timeout -k 10 300 python3 bench.py --gpus 2 --workload $W --steps 200 --warmup 20 > "$OUT/bench_2rank_$W.json" 2> "$OUT/bench_2rank_$W.err" || echo "2-rank $W failed"
 done
 echo "== parity margins"; date
-timeout -k 10 300 python3 -m pytest tests -m gpu -q -s -k "config5_checkpoint" 2>&1 | grep PARITY_MARGIN > "$OUT/parity_margins.txt"
+timeout -k 10 300 python3 -m pytest tests -m gpu -q -s -k "config5_checkpoint or two_term" 2>&1 | grep PARITY_MARGIN > "$OUT/parity_margins.txt"
 du -sh "$OUT"; ls "$OUT"
 date
